@@ -1,0 +1,69 @@
+"""Pins the CPU oracle (oracle/) on the reference's own golden vectors
+(reference tests: test/core_tests.cpp:77-116 Single, :164-195 Board, :197-228 Multi).
+
+ids / counts / corner order: exact.  Sub-pixel corners: <= 1e-3 px absolute (measured 2.5e-4; the reference
+fits lines with a float32 SVD, the oracle in double).  rvec/tvec: <= 1e-4 relative (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.util import load_case, rel_err
+
+CORNER_ABS_TOL = 1e-3
+POSE_REL_TOL = 1e-4
+HS = 0.5
+OBJ = [[-HS, -HS, 0], [-HS, HS, 0], [HS, HS, 0], [HS, -HS, 0]]
+
+
+def test_single_golden():
+    gray, doc = load_case("single")
+    intr = doc["intrinsics"]
+    ms = orc.Oracle().detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    exp = doc["markers"]
+    assert [m["id"] for m in ms] == [e["id"] for e in exp]
+    for m, e in zip(ms, exp):
+        assert np.max(np.abs(m["corners"] - np.array(e["corners"]))) < CORNER_ABS_TOL
+        assert rel_err(m["rvec"], e["Rvec"]) < POSE_REL_TOL
+        assert rel_err(m["tvec"], e["Tvec"]) < POSE_REL_TOL
+        # what the reference test asserts: centre, 4 float ULP
+        c = m["corners"].mean(axis=0)
+        ce = np.array(e["corners"], np.float32).mean(axis=0)
+        assert np.allclose(c, ce, rtol=1e-5)
+
+
+def test_single_pnp_only():
+    """solvePnP restatement alone: golden corners in, golden pose out (pins A.9 to ~1e-11)."""
+    _, doc = load_case("single")
+    intr = doc["intrinsics"]
+    for e in doc["markers"]:
+        ok, r, t = orc.solve_pnp(OBJ, e["corners"], intr["K"], intr["dist"])
+        assert ok
+        assert rel_err(r, e["Rvec"]) < 1e-9
+        assert rel_err(t, e["Tvec"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["board", "chessboard"])
+def test_board_golden(name):
+    gray, doc = load_case(name)
+    intr, bc = doc["intrinsics"], doc["board_conf"]
+    ms = orc.Oracle().detect(gray)  # no intrinsics: pure LINES
+    b = orc.board_detect(ms, bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0)
+    exp = doc["markers"]
+    assert [m["id"] for m in b["markers"]] == [e["id"] for e in exp]
+    for m, e in zip(b["markers"], exp):
+        assert np.max(np.abs(m["corners"] - np.array(e["corners"]))) < CORNER_ABS_TOL
+    assert rel_err(b["rvec"], doc["board"]["Rvec"]) < POSE_REL_TOL
+    assert rel_err(b["tvec"], doc["board"]["Tvec"]) < POSE_REL_TOL
+    assert abs(b["prob"] - len(exp) / len(bc["ids"])) < 1e-6
+
+
+def test_board_pnp_only():
+    """Board solvePnP on the golden corners (96 / 28 points) reproduces the golden board pose."""
+    for name in ("board", "chessboard"):
+        _, doc = load_case(name)
+        intr, bc = doc["intrinsics"], doc["board_conf"]
+        ms = [{"id": e["id"], "corners": e["corners"]} for e in doc["markers"]]
+        b = orc.board_detect(ms, bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0)
+        assert rel_err(b["rvec"], doc["board"]["Rvec"]) < 1e-6
+        assert rel_err(b["tvec"], doc["board"]["Tvec"]) < 1e-6
