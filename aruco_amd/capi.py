@@ -1,0 +1,303 @@
+"""ctypes binding of include/arucohip.h (libarucohip.so). Fails loudly when the HIP library is missing —
+there is no CPU fallback on the product path.
+
+Import torch BEFORE this module when both are used in one process: torch bundles its own libamdhip64.so.7 and the
+dynamic loader then resolves libarucohip's dependency to that already-loaded runtime (same SONAME), so device
+pointers and streams can be shared between torch and the library.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from .build import library_path
+
+OK, E_INVALID, E_CAPACITY, E_UNSUPPORTED, E_HIP, E_OVERFLOW, E_BOARD_CONFIG = range(7)
+THRES_FIXED, THRES_ADPT, THRES_CANNY = 0, 1, 2
+CORNER_NONE, CORNER_HARRIS, CORNER_SUBPIX, CORNER_LINES = 0, 1, 2, 3
+BOARD_NONE, BOARD_PIX, BOARD_METERS = -1, 0, 1
+
+_ERR_NAMES = {1: "ARUCOHIP_E_INVALID", 2: "ARUCOHIP_E_CAPACITY", 3: "ARUCOHIP_E_UNSUPPORTED", 4: "ARUCOHIP_E_HIP",
+              5: "ARUCOHIP_E_OVERFLOW", 6: "ARUCOHIP_E_BOARD_CONFIG"}
+
+
+class ArucoHipError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (_ERR_NAMES.get(code, "error"), code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("thres_method", C.c_int32), ("thres_param1_range", C.c_int32), ("thres_param1", C.c_double),
+                ("thres_param2", C.c_double), ("corner_method", C.c_int32), ("warp_size", C.c_int32),
+                ("min_size", C.c_float), ("max_size", C.c_float), ("border_dist", C.c_float),
+                ("use_locked_corners", C.c_int32), ("decoder_kind", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class Marker(C.Structure):
+    _fields_ = [("id", C.c_int32), ("corners", C.c_float * 8), ("ssize", C.c_float), ("has_pose", C.c_int32),
+                ("pad_", C.c_int32), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3)]
+
+
+class BoardOut(C.Structure):
+    _fields_ = [("n_markers", C.c_int32), ("has_pose", C.c_int32), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
+                ("max_thres_planes", C.c_int32), ("triggers_per_frame", C.c_int32), ("contours_per_frame", C.c_int32),
+                ("points_per_frame", C.c_int32), ("candidates_per_frame", C.c_int32), ("markers_per_frame", C.c_int32)]
+
+
+MARKER_DTYPE = np.dtype([("id", "<i4"), ("corners", "<f4", (8,)), ("ssize", "<f4"), ("has_pose", "<i4"),
+                         ("pad_", "<i4"), ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,))])
+assert MARKER_DTYPE.itemsize == 96 and C.sizeof(Marker) == 96
+
+# every symbol include/arucohip.h declares
+SYMBOLS = [
+    "arucohip_version", "arucohip_default_params", "arucohip_default_limits", "arucohip_create", "arucohip_create_ex",
+    "arucohip_destroy", "arucohip_set_params", "arucohip_get_params", "arucohip_last_error_string", "arucohip_set_stream",
+    "arucohip_get_stream", "arucohip_synchronize", "arucohip_detect", "arucohip_detect_batch", "arucohip_batch_status",
+    "arucohip_get_thresholded", "arucohip_get_candidates", "arucohip_threshold", "arucohip_detect_rectangles",
+    "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
+    "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
+    "arucohip_enable_timing",
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libarucohip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if "torch" not in sys.modules:
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7; when torch is importable load it first so
+        # that libarucohip binds to the same runtime (two runtimes in one process cannot both own the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    if not os.path.exists(path):
+        raise ArucoHipError(E_HIP, "libarucohip.so is not built (%s); run aruco_amd.build_library()" % path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L.arucohip_last_error_string.restype = C.c_char_p
+    L.arucohip_stage_name.restype = C.c_char_p
+    L.arucohip_get_stream.restype = C.c_void_p
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.arucohip_create.argtypes = [vp, i, i, i, i, vp]
+    L.arucohip_create_ex.argtypes = [vp, i, vp, vp]
+    L.arucohip_destroy.argtypes = [vp]
+    L.arucohip_set_params.argtypes = [vp, vp]
+    L.arucohip_get_params.argtypes = [vp, vp]
+    L.arucohip_last_error_string.argtypes = [vp]
+    L.arucohip_set_stream.argtypes = [vp, vp]
+    L.arucohip_get_stream.argtypes = [vp]
+    L.arucohip_synchronize.argtypes = [vp]
+    L.arucohip_detect.argtypes = [vp, vp, i, i, sz, vp, vp, i, f, i, vp, i, vp]
+    L.arucohip_detect_batch.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i]
+    L.arucohip_batch_status.argtypes = [vp]
+    L.arucohip_get_thresholded.argtypes = [vp, i, vp]
+    L.arucohip_get_candidates.argtypes = [vp, i, vp, i, vp]
+    L.arucohip_threshold.argtypes = [vp, i, vp, i, i, sz, C.c_double, C.c_double, vp]
+    L.arucohip_detect_rectangles.argtypes = [vp, vp, i, i, sz, vp, i, vp]
+    L.arucohip_warp.argtypes = [vp, vp, i, i, sz, vp, i, vp]
+    L.arucohip_debug_num_contours.argtypes = [vp, i, vp]
+    L.arucohip_debug_contour.argtypes = [vp, i, i, vp, vp, vp, vp, i, vp]
+    L.arucohip_debug_candidates.argtypes = [vp, i, vp, vp, vp, i, vp]
+    L.arucohip_board_detect.argtypes = [vp, vp, i, vp, vp, i, i, vp, vp, i, f, f, i, vp, vp, vp]
+    L.arucohip_calculate_extrinsics.argtypes = [vp, vp, i, vp, vp, i, f, i]
+    L.arucohip_stage_times.argtypes = [vp, vp, i]
+    L.arucohip_stage_name.argtypes = [i]
+    L.arucohip_enable_timing.argtypes = [vp, i]
+    L.arucohip_default_params.argtypes = [vp]
+    L.arucohip_default_limits.argtypes = [vp, i, i, i]
+    _lib = L
+    return L
+
+
+def default_params():
+    p = Params()
+    load().arucohip_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Handle:
+    """Owns one arucohip_handle (one HIP stream + device buffers)."""
+
+    def __init__(self, max_width, max_height, max_batch=1, device=0, params=None, limits=None):
+        self.L = load()
+        self.h = C.c_void_p()
+        p = params if params is not None else default_params()
+        if limits is None:
+            rc = self.L.arucohip_create(C.byref(p), device, max_width, max_height, max_batch, C.byref(self.h))
+        else:
+            rc = self.L.arucohip_create_ex(C.byref(p), device, C.byref(limits), C.byref(self.h))
+        if rc != OK:
+            raise ArucoHipError(rc, "arucohip_create")
+        self.max_batch = max_batch
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.arucohip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != OK and rc not in allow:
+            raise ArucoHipError(rc, (self.L.arucohip_last_error_string(self.h) or b"").decode())
+        return rc
+
+    def get_params(self):
+        p = Params()
+        self._chk(self.L.arucohip_get_params(self.h, C.byref(p)))
+        return p
+
+    def set_params(self, p):
+        self._chk(self.L.arucohip_set_params(self.h, C.byref(p)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.arucohip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def get_stream(self):
+        return self.L.arucohip_get_stream(self.h)
+
+    def synchronize(self):
+        self._chk(self.L.arucohip_synchronize(self.h))
+
+    # ---- host-buffer API
+    def detect(self, gray, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = g.shape
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros(cap, MARKER_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_detect(self.h, _ptr(g), w, h, w, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                         float(marker_size), int(bool(y_perp)), _ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def detect_batch_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf, h, w = fr.shape
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((nf, cap), MARKER_DTYPE)
+        n = np.zeros(nf, np.int32)
+        self._chk(self.L.arucohip_detect_batch(self.h, _ptr(fr), nf, w, h, w, w * h, 0, _ptr(Ka), _ptr(da),
+                                               0 if da is None else da.size, float(marker_size), int(bool(y_perp)), _ptr(out),
+                                               cap, _ptr(n), 0))
+        return [out[f, :n[f]].copy() for f in range(nf)]
+
+    # ---- device-pointer API (frames resident in HBM, results left in HBM): pointers are plain integers
+    def detect_batch_device(self, frames_ptr, nframes, width, height, out_ptr, cap, n_out_ptr, K=None, dist=None,
+                            marker_size=-1.0, y_perp=False, row_stride=None, frame_stride=None):
+        Ka, da = _f32(K), _f32(dist)
+        rs = width if row_stride is None else row_stride
+        fs = rs * height if frame_stride is None else frame_stride
+        self._chk(self.L.arucohip_detect_batch(self.h, C.c_void_p(frames_ptr), nframes, width, height, rs, fs, 1, _ptr(Ka),
+                                               _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
+                                               C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1))
+
+    def batch_status(self):
+        return self._chk(self.L.arucohip_batch_status(self.h))
+
+    def thresholded(self, frame=0, shape=None):
+        out = np.empty(shape, np.uint8)
+        self._chk(self.L.arucohip_get_thresholded(self.h, frame, _ptr(out)))
+        return out
+
+    def candidates(self, frame=0, cap=512):
+        q = np.zeros((cap, 4, 2), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_get_candidates(self.h, frame, _ptr(q), cap, C.byref(n)))
+        return q[:n.value].copy()
+
+    def debug_candidates(self, frame=0, cap=512):
+        q = np.zeros((cap, 4, 2), np.float32)
+        ids = np.zeros(cap, np.int32)
+        nrot = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_debug_candidates(self.h, frame, _ptr(q), _ptr(ids), _ptr(nrot), cap, C.byref(n)))
+        k = n.value
+        return q[:k].copy(), ids[:k].copy(), nrot[:k].copy()
+
+    def debug_contours(self, frame=0):
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_debug_num_contours(self.h, frame, C.byref(n)))
+        res = []
+        for i in range(n.value):
+            hole, sx, sy, npts = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            self._chk(self.L.arucohip_debug_contour(self.h, frame, i, C.byref(hole), C.byref(sx), C.byref(sy), None, 0, C.byref(npts)))
+            pts = np.zeros((npts.value, 2), np.int16)
+            self._chk(self.L.arucohip_debug_contour(self.h, frame, i, C.byref(hole), C.byref(sx), C.byref(sy), _ptr(pts),
+                                                    npts.value, C.byref(npts)))
+            res.append({"hole": hole.value, "start": (sx.value, sy.value), "pts": pts.astype(np.int32)})
+        return res
+
+    def threshold(self, gray, method=THRES_ADPT, param1=-1.0, param2=-1.0):
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = g.shape
+        out = np.empty((h, w), np.uint8)
+        self._chk(self.L.arucohip_threshold(self.h, method, _ptr(g), w, h, w, float(param1), float(param2), _ptr(out)))
+        return out
+
+    def detect_rectangles(self, thres, cap=512):
+        t = np.ascontiguousarray(thres, dtype=np.uint8)
+        h, w = t.shape
+        q = np.zeros((cap, 4, 2), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_detect_rectangles(self.h, _ptr(t), w, h, w, _ptr(q), cap, C.byref(n)))
+        return q[:n.value].copy()
+
+    def warp(self, gray, quad, size=56):
+        g = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = g.shape
+        q = _f32(quad).reshape(8)
+        out = np.empty((size, size), np.uint8)
+        self._chk(self.L.arucohip_warp(self.h, _ptr(g), w, h, w, _ptr(q), size, _ptr(out)))
+        return out
+
+    def calculate_extrinsics(self, markers, K, dist, marker_size, y_perp=False):
+        m = np.ascontiguousarray(markers, dtype=MARKER_DTYPE).copy()
+        Ka, da = _f32(K), _f32(dist)
+        self._chk(self.L.arucohip_calculate_extrinsics(self.h, _ptr(m), len(m), _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                                       float(marker_size), int(bool(y_perp))))
+        return m
+
+    def board_detect(self, markers, ids, obj, info_type, K=None, dist=None, marker_size=-1.0, repj_err_thres=-1.0, y_perp=False):
+        m = np.ascontiguousarray(markers, dtype=MARKER_DTYPE)
+        ida = np.ascontiguousarray(ids, dtype=np.int32)
+        oa = _f32(obj)
+        Ka, da = _f32(K), _f32(dist)
+        outm = np.zeros(max(len(m), 1), MARKER_DTYPE)
+        bo = BoardOut()
+        prob = C.c_float(0)
+        self._chk(self.L.arucohip_board_detect(self.h, _ptr(m) if len(m) else None, len(m), _ptr(ida), _ptr(oa), len(ida), info_type,
+                                               _ptr(Ka), _ptr(da), 0 if da is None else da.size, float(marker_size),
+                                               float(repj_err_thres), int(bool(y_perp)), _ptr(outm), C.byref(bo), C.byref(prob)))
+        return {"prob": prob.value, "markers": outm[:bo.n_markers].copy(), "has_pose": bo.has_pose,
+                "rvec": np.array(bo.rvec), "tvec": np.array(bo.tvec)}
+
+    def enable_timing(self, on=True):
+        self.L.arucohip_enable_timing(self.h, int(on))
+
+    def stage_times(self):
+        ms = (C.c_float * 8)()
+        n = self.L.arucohip_stage_times(self.h, ms, 8)
+        return {self.L.arucohip_stage_name(i).decode(): ms[i] for i in range(n)}

@@ -1,0 +1,721 @@
+// Host side of libarucohip: handle, device buffers, launch order. Implements include/arucohip.h.
+//
+// Launch order of one batch (all on the handle's stream, no host round trip until the final D2H of the markers):
+//   memset counters -> threshold(+masks+start candidates) -> walkers -> contour/quad -> frame candidates ->
+//   warp+decode -> corner refinement (+rotation) -> finalize -> pose
+// which is the stage order of MarkerDetector::detect (/root/reference/src/markerdetector.cpp:302-478).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace ah {
+void launch_rotate_x(hipStream_t s, double* rt);
+}
+
+using namespace ah;
+
+enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_COUNT };
+static const char* kStageNames[STAGE_COUNT] = {"Threshold", "Rectangles", "Identify", "Subpixel", "Filtering"};
+
+struct arucohip_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    arucohip_params_t params;
+    arucohip_limits_t lim;
+    Buffers buf{};
+    uint8_t* d_gray = nullptr;        // staging for host frames
+    size_t gray_bytes = 0;
+    // pinned host staging
+    arucohip_marker_t* h_markers = nullptr;
+    int32_t* h_n = nullptr;
+    uint32_t* h_counters = nullptr;
+    // small device scratch for the stage-level calls
+    float* d_small_f = nullptr;       // 4096 floats
+    double* d_small_d = nullptr;      // 64 doubles
+    int* d_small_i = nullptr;
+    uint8_t* d_patch = nullptr;       // MAX_WARP^2
+    // last call
+    int last_w = 0, last_h = 0, last_frames = 0, last_nthr = 1;
+    const uint8_t* last_gray = nullptr;
+    FrameGeom last_geom{};
+    bool timing = false;
+    hipEvent_t ev[STAGE_COUNT + 1] = {};
+    float stage_ms[STAGE_COUNT] = {};
+    std::string err;
+};
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[256];                                                                     \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (h)->err = buf_;                                                                    \
+            return ARUCOHIP_E_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+static int fail(arucohip_handle* h, int code, const char* msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+extern "C" {
+
+int arucohip_version(void) { return ARUCOHIP_VERSION; }
+
+void arucohip_default_params(arucohip_params_t* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->thres_method = ARUCOHIP_THRES_ADPT;
+    p->thres_param1 = 7, p->thres_param2 = 7, p->thres_param1_range = 0;
+    p->corner_method = ARUCOHIP_CORNER_LINES;
+    p->warp_size = 56;
+    p->min_size = 0.04f, p->max_size = 0.5f;
+    p->border_dist = 0.025f;
+    p->use_locked_corners = 0;
+    p->decoder_kind = ARUCOHIP_DECODER_FIDUCIAL_5X5;
+}
+
+void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height, int max_batch) {
+    l->max_width = max_width, l->max_height = max_height, l->max_batch = std::max(max_batch, 1);
+    l->max_thres_planes = 1;
+    long px = (long)max_width * max_height;
+    l->triggers_per_frame = (int)std::min<long>(std::max<long>(px / 16, 16384), 1 << 20);
+    l->contours_per_frame = 1024;
+    l->points_per_frame = (int)std::min<long>(std::max<long>(px / 8, 65536), 1 << 21);
+    l->candidates_per_frame = 256;
+    l->markers_per_frame = 128;
+}
+
+static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
+    // CV_Assert of setMinMaxSize (markerdetector.cpp:1032-1034) and setWarpSize (:1048)
+    if (!(p->min_size > 0 && p->min_size <= 1) || !(p->max_size > 0 && p->max_size <= 1) || !(p->min_size < p->max_size))
+        return fail(h, ARUCOHIP_E_INVALID, "setMinMaxSize: need 0 < min < max <= 1");
+    if (p->warp_size < 10) return fail(h, ARUCOHIP_E_INVALID, "setWarpSize: need >= 10");
+    if (p->warp_size > 128) return fail(h, ARUCOHIP_E_UNSUPPORTED, "warp size > 128 not supported");
+    if (p->thres_method == ARUCOHIP_THRES_CANNY) return fail(h, ARUCOHIP_E_UNSUPPORTED, "CANNY threshold is not on the accelerated path");
+    if (p->thres_method != ARUCOHIP_THRES_FIXED && p->thres_method != ARUCOHIP_THRES_ADPT) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
+    if (p->corner_method < ARUCOHIP_CORNER_NONE || p->corner_method > ARUCOHIP_CORNER_LINES) return fail(h, ARUCOHIP_E_INVALID, "bad corner method");
+    if (p->use_locked_corners) return fail(h, ARUCOHIP_E_UNSUPPORTED, "locked corners are not on the accelerated path");
+    if (p->decoder_kind != ARUCOHIP_DECODER_FIDUCIAL_5X5) return fail(h, ARUCOHIP_E_UNSUPPORTED, "only the 5x5 fiducial decoder runs on device");
+    if (p->thres_param1_range < 0 || 2 * p->thres_param1_range + 1 > 16) return fail(h, ARUCOHIP_E_UNSUPPORTED, "threshold range too large");
+    if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 > 15) return fail(h, ARUCOHIP_E_UNSUPPORTED, "SUBPIX window > 15");
+    if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 < 1) return fail(h, ARUCOHIP_E_INVALID, "SUBPIX window < 1");
+    return ARUCOHIP_OK;
+}
+
+static void free_all(arucohip_handle* h) {
+    hipSetDevice(h->device);
+    hipFree(h->buf.thres), hipFree(h->buf.nbr), hipFree(h->buf.trig), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
+    hipFree(h->buf.counters), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
+    if (h->h_markers) hipHostFree(h->h_markers);
+    if (h->h_n) hipHostFree(h->h_n);
+    if (h->h_counters) hipHostFree(h->h_counters);
+    for (auto& e : h->ev)
+        if (e) hipEventDestroy(e);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+}
+
+int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* lim, arucohip_handle** out) {
+    if (!out || !lim) return ARUCOHIP_E_INVALID;
+    *out = nullptr;
+    if (lim->max_width < 8 || lim->max_height < 8 || lim->max_width > 32767 || lim->max_height > 32767 || lim->max_batch < 1 ||
+        lim->max_thres_planes < 1 || lim->max_thres_planes > 16 || lim->candidates_per_frame > 512 || lim->markers_per_frame > 256)
+        return ARUCOHIP_E_INVALID;
+    arucohip_handle* h = new arucohip_handle();
+    h->device = device;
+    h->lim = *lim;
+    if (params)
+        h->params = *params;
+    else
+        arucohip_default_params(&h->params);
+    int rc = validate_params(h, &h->params);
+    if (rc != ARUCOHIP_OK) {
+        delete h;
+        return rc;
+    }
+    auto bail = [&](hipError_t e) {
+        fprintf(stderr, "arucohip_create: %s\n", hipGetErrorString(e));
+        free_all(h);
+        delete h;
+        return ARUCOHIP_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    h->stream = h->own_stream;
+    const size_t F = lim->max_batch, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
+    Buffers& b = h->buf;
+    b.cap_trig = (uint32_t)std::min<size_t>(P * lim->triggers_per_frame, 0xFFFFFFF0u);
+    b.cap_cdesc = (uint32_t)std::min<size_t>(P * lim->contours_per_frame, 0xFFFFFFF0u);
+    b.cap_pool = (uint32_t)std::min<size_t>(P * lim->points_per_frame, 0xFFFFFFF0u);
+    b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);
+    b.cap_cands = lim->candidates_per_frame;
+    b.cap_markers = lim->markers_per_frame;
+#define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
+    ALLOC(b.thres, P * px);
+    ALLOC(b.nbr, P * px);
+    ALLOC(b.trig, (size_t)b.cap_trig * sizeof(uint2));
+    ALLOC(b.cdesc, (size_t)b.cap_cdesc * sizeof(ContourDesc));
+    ALLOC(b.pool, (size_t)b.cap_pool * sizeof(short2));
+    ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
+    ALLOC(b.cands, F * b.cap_cands * sizeof(Cand));
+    ALLOC(b.ncands, F * sizeof(int32_t));
+    ALLOC(b.markers, F * b.cap_markers * sizeof(arucohip_marker_t));
+    ALLOC(b.nmarkers, F * sizeof(int32_t));
+    ALLOC(b.counters, (CNT_FIXED + F) * sizeof(uint32_t));
+    ALLOC(h->d_small_f, 8192 * sizeof(float));
+    ALLOC(h->d_small_d, 64 * sizeof(double));
+    ALLOC(h->d_small_i, 64 * sizeof(int));
+    ALLOC(h->d_patch, 128 * 128);
+#undef ALLOC
+    if ((e = hipHostMalloc((void**)&h->h_markers, F * b.cap_markers * sizeof(arucohip_marker_t))) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc((void**)&h->h_n, F * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc((void**)&h->h_counters, (CNT_FIXED + F) * sizeof(uint32_t))) != hipSuccess) return bail(e);
+    for (auto& ev : h->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
+    *out = h;
+    return ARUCOHIP_OK;
+}
+
+int arucohip_create(const arucohip_params_t* params, int device, int max_width, int max_height, int max_batch, arucohip_handle** out) {
+    arucohip_limits_t l;
+    arucohip_default_limits(&l, max_width, max_height, max_batch);
+    if (params) l.max_thres_planes = std::max(1, 2 * params->thres_param1_range + 1);
+    return arucohip_create_ex(params, device, &l, out);
+}
+
+void arucohip_destroy(arucohip_handle* h) {
+    if (!h) return;
+    free_all(h);
+    delete h;
+}
+
+int arucohip_set_params(arucohip_handle* h, const arucohip_params_t* p) {
+    if (!h || !p) return ARUCOHIP_E_INVALID;
+    int rc = validate_params(h, p);
+    if (rc != ARUCOHIP_OK) return rc;
+    if (2 * p->thres_param1_range + 1 > h->lim.max_thres_planes)
+        return fail(h, ARUCOHIP_E_INVALID, "threshold range exceeds the planes this handle was created with");
+    h->params = *p;
+    return ARUCOHIP_OK;
+}
+
+int arucohip_get_params(const arucohip_handle* h, arucohip_params_t* p) {
+    if (!h || !p) return ARUCOHIP_E_INVALID;
+    *p = h->params;
+    return ARUCOHIP_OK;
+}
+
+const char* arucohip_last_error_string(const arucohip_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int arucohip_set_stream(arucohip_handle* h, void* s) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return ARUCOHIP_OK;
+}
+void* arucohip_get_stream(arucohip_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int arucohip_synchronize(arucohip_handle* h) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+int arucohip_enable_timing(arucohip_handle* h, int on) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    h->timing = on != 0;
+    return ARUCOHIP_OK;
+}
+const char* arucohip_stage_name(int i) { return (i >= 0 && i < STAGE_COUNT) ? kStageNames[i] : ""; }
+int arucohip_stage_times(arucohip_handle* h, float* ms, int cap) {
+    if (!h) return 0;
+    for (int i = 0; i < STAGE_COUNT && i < cap; i++) ms[i] = h->stage_ms[i];
+    return STAGE_COUNT;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+static int make_detect_params(arucohip_handle* h, int W, int H, DetectParams* dp) {
+    const arucohip_params_t& p = h->params;
+    std::memset(dp, 0, sizeof(*dp));
+    dp->thres_method = p.thres_method;
+    dp->nthr = 2 * p.thres_param1_range + 1;
+    if (dp->nthr > h->lim.max_thres_planes) return fail(h, ARUCOHIP_E_INVALID, "threshold range exceeds handle planes");
+    for (int i = 0; i < dp->nthr; i++) {
+        // markerdetector.cpp:325-333 (step is the range itself) and the odd/>=3 fix-up of :657-660
+        double p1 = dp->nthr == 1 ? p.thres_param1 : p.thres_param1 - p.thres_param1_range + (double)p.thres_param1_range * i;
+        if (p.thres_method == ARUCOHIP_THRES_ADPT) {
+            if (p1 < 3)
+                p1 = 3;
+            else if (((int)p1) % 2 != 1)
+                p1 = (int)(p1 + 1);
+            dp->block[i] = (int)p1;
+            if (dp->block[i] > 31) return fail(h, ARUCOHIP_E_UNSUPPORTED, "adaptive threshold block size > 31");
+        }
+        dp->p1[i] = p1;
+    }
+    dp->idelta = (int)std::floor(p.thres_param2);
+    dp->corner_method = p.corner_method;
+    dp->warp_size = p.warp_size;
+    dp->min_contour = (int)(p.min_size * std::max(W, H) * 4);   // :500-501, float arithmetic
+    dp->max_contour = (int)(p.max_size * std::max(W, H) * 4);
+    if (dp->max_contour > 32760) dp->max_contour = 32760;       // contour points live in LDS as short2
+    // :433-434 Rect(Point(size)*t, Point(size)*(1-t)) with cvRound
+    int x1 = (int)lrintf((float)W * p.border_dist), y1 = (int)lrintf((float)H * p.border_dist);
+    int x2 = (int)lrintf((float)W * (1.0f - p.border_dist)), y2 = (int)lrintf((float)H * (1.0f - p.border_dist));
+    dp->bx0 = std::min(x1, x2), dp->by0 = std::min(y1, y2);
+    dp->bx1 = std::max(x1, x2), dp->by1 = std::max(y1, y2);
+    dp->subpix_win = (int)p.thres_param1;
+    return ARUCOHIP_OK;
+}
+
+static int make_cam(arucohip_handle* h, const float* K, const float* dist, int ndist, float marker_size, int y_perp, CamModel* cam) {
+    std::memset(cam, 0, sizeof(*cam));
+    if (ndist < 0 || ndist > 8) return fail(h, ARUCOHIP_E_INVALID, "ndist must be 0..8");
+    cam->has_K = K != nullptr;
+    if (K)
+        for (int i = 0; i < 9; i++) cam->K[i] = K[i];
+    cam->has_dist = dist != nullptr && ndist > 0;
+    if (cam->has_dist)
+        for (int i = 0; i < ndist; i++) cam->k[i] = (double)dist[i];
+    cam->marker_size = marker_size;
+    cam->y_perp = y_perp;
+    return ARUCOHIP_OK;
+}
+
+static int check_status(arucohip_handle* h, uint32_t st) {
+    if (!st) return ARUCOHIP_OK;
+    char msg[256];
+    snprintf(msg, sizeof(msg), "device list overflow:%s%s%s%s%s%s", (st & ST_TRIG_OVERFLOW) ? " triggers" : "",
+             (st & ST_CDESC_OVERFLOW) ? " contours" : "", (st & ST_POOL_OVERFLOW) ? " points" : "",
+             (st & ST_QUAD_OVERFLOW) ? " quads" : "", (st & ST_CAND_OVERFLOW) ? " candidates" : "",
+             (st & ST_MARKER_OVERFLOW) ? " markers" : "");
+    h->err = msg;
+    return ARUCOHIP_E_OVERFLOW;
+}
+
+// runs kernels 2..8 after the masks and start candidates exist
+static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
+    launch_walkers(h->stream, g, dp, h->buf);
+    launch_contour_quads(h->stream, g, nframes, dp, h->buf);
+    launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
+}
+
+static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp, const CamModel& cam) {
+    hipStream_t s = h->stream;
+    Buffers& b = h->buf;
+    HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
+    if (h->timing) hipEventRecord(h->ev[0], s);
+    launch_threshold(s, gray_dev, g, nframes, dp, b);
+    if (h->timing) hipEventRecord(h->ev[1], s);
+    run_rectangles(h, g, nframes, dp);
+    if (h->timing) hipEventRecord(h->ev[2], s);
+    launch_decode(s, gray_dev, g, nframes, dp, b);
+    launch_refine_lines(s, g, nframes, dp, cam, b);
+    if (h->timing) hipEventRecord(h->ev[3], s);
+    if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX)
+        launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
+    if (h->timing) hipEventRecord(h->ev[4], s);
+    launch_finalize(s, g, nframes, dp, cam, b);
+    if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
+    if (h->timing) hipEventRecord(h->ev[5], s);
+    HIPCHK(h, hipGetLastError());
+    h->last_w = g.width, h->last_h = g.height, h->last_frames = nframes, h->last_nthr = dp.nthr;
+    h->last_gray = gray_dev, h->last_geom = g;
+    return ARUCOHIP_OK;
+}
+
+static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                        int on_device, const uint8_t** gray_dev, FrameGeom* g) {
+    g->width = W, g->height = H;
+    if (on_device) {
+        *gray_dev = frames;
+        g->row_stride = row_stride, g->frame_stride = frame_stride;
+        return ARUCOHIP_OK;
+    }
+    size_t need = (size_t)nframes * W * H;
+    if (need > h->gray_bytes) {
+        if (h->d_gray) HIPCHK(h, hipFree(h->d_gray));
+        h->d_gray = nullptr, h->gray_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_gray, need));
+        h->gray_bytes = need;
+    }
+    for (int f = 0; f < nframes; f++)
+        HIPCHK(h, hipMemcpy2DAsync(h->d_gray + (size_t)f * W * H, W, frames + (size_t)f * frame_stride, row_stride, W, H,
+                                   hipMemcpyHostToDevice, h->stream));
+    *gray_dev = h->d_gray;
+    g->row_stride = W, g->frame_stride = (size_t)W * H;
+    return ARUCOHIP_OK;
+}
+
+static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride) {
+    if (nframes < 1 || nframes > h->lim.max_batch) return fail(h, ARUCOHIP_E_INVALID, "nframes outside 1..max_batch");
+    if (W < 8 || H < 8 || (size_t)W * H > (size_t)h->lim.max_width * h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame larger than the handle was created for");
+    if (row_stride < (size_t)W) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width");
+    return ARUCOHIP_OK;
+}
+
+extern "C" {
+
+int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                          int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                          arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
+    if (!h || !frames || !n_out || (cap > 0 && !out) || cap < 0) return ARUCOHIP_E_INVALID;
+    int rc = check_geometry(h, nframes, W, H, row_stride);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    DetectParams dp;
+    CamModel cam;
+    if ((rc = make_detect_params(h, W, H, &dp))) return rc;
+    if ((rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam))) return rc;
+    const uint8_t* gray_dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, &gray_dev, &g))) return rc;
+    if ((rc = detect_core(h, gray_dev, g, nframes, dp, cam))) return rc;
+    const Buffers& b = h->buf;
+    const int ncopy = std::min(cap, b.cap_markers);
+    if (out_on_device) {
+        if (ncopy > 0)
+            HIPCHK(h, hipMemcpy2DAsync(out, (size_t)cap * sizeof(arucohip_marker_t), b.markers, (size_t)b.cap_markers * sizeof(arucohip_marker_t),
+                                       (size_t)ncopy * sizeof(arucohip_marker_t), nframes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(n_out, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        return ARUCOHIP_OK;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_markers, b.markers, (size_t)nframes * b.cap_markers * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_n, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->timing)
+        for (int i = 0; i < STAGE_COUNT; i++) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
+    int ret = check_status(h, h->h_counters[CNT_STATUS] & ~(uint32_t)ST_MARKER_OVERFLOW);
+    for (int f = 0; f < nframes; f++) {
+        int n = h->h_n[f];
+        n_out[f] = n;
+        if (n > cap) {
+            if (ret == ARUCOHIP_OK) ret = fail(h, ARUCOHIP_E_CAPACITY, "marker output array too small");
+            n = cap;
+        }
+        n = std::min(n, b.cap_markers);
+        if (n > 0) std::memcpy(out + (size_t)f * cap, h->h_markers + (size_t)f * b.cap_markers, (size_t)n * sizeof(arucohip_marker_t));
+    }
+    return ret;
+}
+
+int arucohip_batch_status(arucohip_handle* h) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->timing)
+        for (int i = 0; i < STAGE_COUNT; i++) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
+    return check_status(h, h->h_counters[CNT_STATUS]);
+}
+
+int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t row_stride, const float* K, const float* dist, int ndist,
+                    float marker_size, int y_perp, arucohip_marker_t* out, int cap, int* n_out) {
+    int32_t n = 0;
+    int rc = arucohip_detect_batch(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, K, dist, ndist, marker_size, y_perp, out, cap, &n, 0);
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst) {
+    if (!h || !dst || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t px = (size_t)h->last_w * h->last_h;
+    int plane = frame * h->last_nthr + h->last_nthr / 2;   // thres = thres_images[n_param1 / 2]
+    HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres + plane * px, px, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+static int fetch_cands(arucohip_handle* h, int frame, std::vector<Cand>* v) {
+    if (!h || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int32_t n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, h->buf.ncands + frame, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    v->resize(std::max(n, 0));
+    if (n > 0) {
+        HIPCHK(h, hipMemcpyAsync(v->data(), h->buf.cands + (size_t)frame * h->buf.cap_cands, n * sizeof(Cand), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return ARUCOHIP_OK;
+}
+
+int arucohip_get_candidates(arucohip_handle* h, int frame, float* quads, int cap, int* n) {
+    std::vector<Cand> v;
+    int rc = fetch_cands(h, frame, &v);
+    if (rc) return rc;
+    int k = 0;
+    for (auto& c : v) {
+        if (c.id != -1) continue;
+        if (k < cap)
+            for (int i = 0; i < 8; i++) quads[k * 8 + i] = c.c[i];
+        k++;
+    }
+    if (n) *n = k;
+    return k > cap ? ARUCOHIP_E_CAPACITY : ARUCOHIP_OK;
+}
+
+int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int32_t* ids, int32_t* nrot, int cap, int* n) {
+    std::vector<Cand> v;
+    int rc = fetch_cands(h, frame, &v);
+    if (rc) return rc;
+    int k = 0;
+    for (auto& c : v) {
+        if (k < cap) {
+            for (int i = 0; i < 4; i++) quads0[k * 8 + 2 * i] = c.qx[i], quads0[k * 8 + 2 * i + 1] = c.qy[i];
+            if (ids) ids[k] = c.id;
+            if (nrot) nrot[k] = c.nrot;
+        }
+        k++;
+    }
+    if (n) *n = k;
+    return k > cap ? ARUCOHIP_E_CAPACITY : ARUCOHIP_OK;
+}
+
+// contours of one frame in reference (RETR_LIST) order: planes ascending, raster key descending
+static int fetch_contours(arucohip_handle* h, int frame, std::vector<ContourDesc>* out) {
+    if (!h || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    uint32_t cnt[CNT_FIXED];
+    HIPCHK(h, hipMemcpyAsync(cnt, h->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint32_t n = std::min(cnt[CNT_CDESC], h->buf.cap_cdesc);
+    std::vector<ContourDesc> all(n);
+    if (n) {
+        HIPCHK(h, hipMemcpyAsync(all.data(), h->buf.cdesc, n * sizeof(ContourDesc), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    out->clear();
+    for (auto& c : all)
+        if (c.plane / h->last_nthr == frame && c.n > 0) out->push_back(c);
+    std::sort(out->begin(), out->end(), [](const ContourDesc& a, const ContourDesc& b) {
+        if (a.plane != b.plane) return a.plane < b.plane;
+        return a.key > b.key;
+    });
+    return ARUCOHIP_OK;
+}
+
+int arucohip_debug_num_contours(arucohip_handle* h, int frame, int* n) {
+    std::vector<ContourDesc> v;
+    int rc = fetch_contours(h, frame, &v);
+    if (rc) return rc;
+    *n = (int)v.size();
+    return ARUCOHIP_OK;
+}
+
+int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hole, int* sx, int* sy, int16_t* xy, int cap_points, int* n_points) {
+    std::vector<ContourDesc> v;
+    int rc = fetch_contours(h, frame, &v);
+    if (rc) return rc;
+    if (index < 0 || index >= (int)v.size()) return ARUCOHIP_E_INVALID;
+    const ContourDesc& c = v[index];
+    if (is_hole) *is_hole = c.hole;
+    if (sx) *sx = c.x0;
+    if (sy) *sy = c.y0;
+    if (n_points) *n_points = c.n;
+    if (xy && cap_points >= c.n) {
+        HIPCHK(h, hipMemcpyAsync(xy, h->buf.pool + c.pool_off, (size_t)c.n * sizeof(short2), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else if (xy) {
+        return ARUCOHIP_E_CAPACITY;
+    }
+    return ARUCOHIP_OK;
+}
+
+// ---- stage entry points (markerdetector.h:255-280)
+int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int W, int H, size_t row_stride, double param1, double param2, uint8_t* dst) {
+    if (!h || !gray || !dst) return ARUCOHIP_E_INVALID;
+    int rc = check_geometry(h, 1, W, H, row_stride);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    arucohip_params_t saved = h->params;
+    arucohip_params_t p = saved;
+    p.thres_method = method;
+    if (param1 != -1) p.thres_param1 = param1;   // thresHold(): -1 selects the configured value (:646-649)
+    if (param2 != -1) p.thres_param2 = param2;
+    p.thres_param1_range = 0;
+    if ((rc = validate_params(h, &p))) return rc;
+    h->params = p;
+    DetectParams dp;
+    rc = make_detect_params(h, W, H, &dp);
+    h->params = saved;
+    if (rc) return rc;
+    const uint8_t* gray_dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &gray_dev, &g))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
+    launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1;
+    return ARUCOHIP_OK;
+}
+
+int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, int H, size_t row_stride, float* quads, int cap, int* n) {
+    if (!h || !thres || !n) return ARUCOHIP_E_INVALID;
+    int rc = check_geometry(h, 1, W, H, row_stride);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    DetectParams dp;
+    arucohip_params_t saved = h->params;
+    h->params.thres_param1_range = 0;
+    rc = make_detect_params(h, W, H, &dp);
+    h->params = saved;
+    if (rc) return rc;
+    const uint8_t* dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
+    launch_binary_planes(h->stream, dev, g, 1, h->buf);
+    run_rectangles(h, g, 1, dp);
+    HIPCHK(h, hipGetLastError());
+    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1;
+    std::vector<Cand> v;
+    if ((rc = fetch_cands(h, 0, &v))) return rc;
+    HIPCHK(h, hipMemcpy(h->h_counters, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ((rc = check_status(h, h->h_counters[CNT_STATUS]))) return rc;
+    *n = (int)v.size();
+    for (int k = 0; k < (int)v.size() && k < cap; k++)
+        for (int i = 0; i < 8; i++) quads[k * 8 + i] = v[k].c[i];
+    return (int)v.size() > cap ? ARUCOHIP_E_CAPACITY : ARUCOHIP_OK;
+}
+
+int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t row_stride, const float quad[8], int size, uint8_t* dst) {
+    if (!h || !gray || !quad || !dst) return ARUCOHIP_E_INVALID;
+    if (size < 1 || size > 128) return fail(h, ARUCOHIP_E_INVALID, "warp size outside 1..128");
+    int rc = check_geometry(h, 1, W, H, row_stride);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint8_t* dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_small_f, quad, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    launch_warp_only(h->stream, dev, g, h->d_small_f, size, h->d_patch);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(dst, h->d_patch, (size_t)size * size, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers, int n, const float* K, const float* dist, int ndist,
+                                  float marker_size, int y_perp) {
+    if (!h || !markers || n < 0 || !K) return ARUCOHIP_E_INVALID;
+    if (!(marker_size > 0)) return fail(h, ARUCOHIP_E_INVALID, "marker size must be positive");   // marker.cpp:114
+    if (n == 0) return ARUCOHIP_OK;
+    if ((size_t)n > (size_t)h->lim.max_batch * h->buf.cap_markers) return fail(h, ARUCOHIP_E_CAPACITY, "too many markers for this handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    CamModel cam;
+    int rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->buf.markers, markers, (size_t)n * sizeof(arucohip_marker_t), hipMemcpyHostToDevice, h->stream));
+    launch_marker_pose(h->stream, h->buf.markers, n, cam);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(markers, h->buf.markers, (size_t)n * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+// BoardDetector::detect (boarddetector.cpp:90-205). The id filter and point gathering are a few hundred bytes of host
+// glue; both solvePnP calls and the reprojection run on the device.
+int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, int n, const int32_t* ids, const float* obj, int nboard,
+                          int info_type, const float* K, const float* dist, int ndist, float marker_size, float repj_err_thres, int y_perp,
+                          arucohip_marker_t* out_markers, arucohip_board_t* out, float* prob) {
+    if (!h || !out || !prob || n < 0 || (n > 0 && (!markers || !out_markers))) return ARUCOHIP_E_INVALID;
+    if (nboard <= 0 || !ids || !obj) return fail(h, ARUCOHIP_E_BOARD_CONFIG, "invalid BoardConfig that is empty");
+    std::memset(out, 0, sizeof(*out));
+    *prob = 0;
+    auto onorm = [&](int a, int b) {
+        // Point3f difference in float, cv::norm in double
+        float dx = obj[3 * a] - obj[3 * b], dy = obj[3 * a + 1] - obj[3 * b + 1], dz = obj[3 * a + 2] - obj[3 * b + 2];
+        return std::sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+    };
+    float ssize = -1;
+    if (info_type == ARUCOHIP_BOARD_PIX && marker_size > 0)
+        ssize = marker_size;
+    else if (info_type == ARUCOHIP_BOARD_METERS)
+        ssize = (float)onorm(0, 1);
+    std::vector<int> slot;
+    int nb = 0;
+    for (int i = 0; i < n; i++) {
+        const int32_t* f = std::find(ids, ids + nboard, markers[i].id);
+        if (f == ids + nboard) continue;
+        out_markers[nb] = markers[i];
+        out_markers[nb].ssize = ssize;
+        slot.push_back((int)(f - ids));
+        nb++;
+    }
+    out->n_markers = nb;
+    if (nb == 0 || !K) return ARUCOHIP_OK;
+    bool enough = (marker_size > 0 && info_type == ARUCOHIP_BOARD_PIX) || info_type == ARUCOHIP_BOARD_METERS;
+    if (!enough) return ARUCOHIP_OK;
+    double mpp = info_type == ARUCOHIP_BOARD_PIX ? marker_size / onorm(0, 1) : 1;
+    std::vector<float> o3, i2;
+    for (int i = 0; i < nb; i++)
+        for (int p = 0; p < 4; p++) {
+            i2.push_back(out_markers[i].corners[2 * p]), i2.push_back(out_markers[i].corners[2 * p + 1]);
+            const float* q = obj + ((size_t)slot[i] * 4 + p) * 3;
+            for (int c = 0; c < 3; c++) o3.push_back((float)(q[c] * mpp));
+        }
+    int npts = nb * 4;
+    if (npts * 5 > 8192) return fail(h, ARUCOHIP_E_CAPACITY, "board with too many points");
+    HIPCHK(h, hipSetDevice(h->device));
+    float zeros[4] = {0, 0, 0, 0};
+    if (!dist || ndist == 0) dist = zeros, ndist = 4;
+    CamModel cam;
+    int rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam);
+    if (rc) return rc;
+    float* d_obj = h->d_small_f;
+    float* d_img = h->d_small_f + 3 * npts;
+    double rt[6];
+    int ok = 0;
+    auto solve = [&](int m) -> int {
+        HIPCHK(h, hipMemcpyAsync(d_obj, o3.data(), 3 * m * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_img, i2.data(), 2 * m * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        launch_pnp_points(h->stream, d_obj, d_img, m, cam, h->d_small_d, h->d_small_i);
+        HIPCHK(h, hipGetLastError());
+        return ARUCOHIP_OK;
+    };
+    if ((rc = solve(npts))) return rc;
+    if (repj_err_thres > 0) {
+        std::vector<float> rp(2 * npts);
+        launch_project_points(h->stream, d_obj, npts, h->d_small_d, cam, d_img + 2 * npts);
+        HIPCHK(h, hipMemcpyAsync(rp.data(), d_img + 2 * npts, 2 * npts * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<float> o3f, i2f;
+        for (int i = 0; i < npts; i++) {
+            float dx = rp[2 * i] - i2[2 * i], dy = rp[2 * i + 1] - i2[2 * i + 1];
+            float err = (float)std::sqrt((double)dx * dx + (double)dy * dy);
+            if (err < repj_err_thres) {
+                for (int c = 0; c < 3; c++) o3f.push_back(o3[3 * i + c]);
+                i2f.push_back(i2[2 * i]), i2f.push_back(i2[2 * i + 1]);
+            }
+        }
+        o3.swap(o3f), i2.swap(i2f);
+        if ((rc = solve((int)(i2.size() / 2)))) return rc;
+    }
+    if (y_perp) launch_rotate_x(h->stream, h->d_small_d);
+    HIPCHK(h, hipMemcpyAsync(rt, h->d_small_d, sizeof(rt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&ok, h->d_small_i, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out->has_pose = ok;
+    for (int k = 0; k < 3; k++) out->rvec[k] = rt[k], out->tvec[k] = rt[3 + k];
+    *prob = float(nb) / float(nboard);
+    return ARUCOHIP_OK;
+}
+
+}  // extern "C"

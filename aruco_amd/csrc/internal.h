@@ -1,0 +1,124 @@
+// Internal device-side data layout of libarucohip (MI355X / gfx950). Not part of the C ABI.
+//
+// HBM layout per handle (F = frames in the batch, T = threshold planes per frame, P = F*T planes):
+//   thres [P][H][W] u8   thresholded image (API-visible product, MarkerDetector::getThresholdedImage)
+//   nbr   [P][H][W] u8   bit d set = 8-neighbour in direction d (0=E,1=NE,..7=SE, y down) is foreground, after the
+//                        1-px frame has been zeroed the way cv::findContours does
+//   trig  u32x2 list     border-start candidates {plane<<1|hole, y<<16|x}
+//   cdesc list           borders that passed the size filter {plane, start, hole, n, key, pool offset}
+//   pool  short2 list    contour points
+//   quads [F][capQ]      4-vertex convex polygons
+//   cands [F][capC]      ordered candidates with decode result and refined corners
+//   markers [F][capM]    arucohip_marker_t
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/arucohip.h"
+
+namespace ah {
+
+constexpr int WAVE = 64;
+
+enum Counter {
+    CNT_TRIG = 0,      // number of entries in trig list
+    CNT_CDESC = 1,     // number of contour descriptors
+    CNT_POOL = 2,      // contour points allocated
+    CNT_STATUS = 3,    // overflow bit flags
+    CNT_FIXED = 8      // per-frame counters follow: [CNT_FIXED + f] = quads of frame f
+};
+
+enum StatusBits {
+    ST_TRIG_OVERFLOW = 1,
+    ST_CDESC_OVERFLOW = 2,
+    ST_POOL_OVERFLOW = 4,
+    ST_QUAD_OVERFLOW = 8,
+    ST_CAND_OVERFLOW = 16,
+    ST_MARKER_OVERFLOW = 32,
+};
+
+struct ContourDesc {
+    int32_t plane;     // frame*T + t
+    int16_t x0, y0;    // start pixel
+    int32_t hole;
+    int32_t n;         // number of points
+    uint32_t key;      // raster index of the scan transition (y*W + x_trigger)
+    uint32_t pool_off; // first point in pool
+};
+
+struct Quad {
+    int16_t x[4], y[4];
+    int32_t cdesc;     // index into cdesc list
+    uint32_t key;      // ordering key inside the frame: t << 26 | (0x3FFFFFF - raster)  (ascending = reference order)
+    int32_t pad_;
+};
+
+struct Cand {
+    float c[8];        // current corners (x0,y0,...)
+    int16_t qx[4], qy[4];  // integer corners after orientation normalisation (detectRectangles output)
+    int32_t cdesc;
+    int32_t swapped;   // contour must be read reversed
+    int32_t id;        // -1 = not a marker
+    int32_t nrot;
+};
+
+struct FrameGeom {
+    int width, height;
+    size_t row_stride, frame_stride;   // of the input gray frames
+};
+
+struct CamModel {
+    int has_K, has_dist;
+    float K[9];
+    double k[8];       // k1,k2,p1,p2,k3,k4,k5,k6 (zero padded)
+    float marker_size;
+    int y_perp;
+};
+
+struct DetectParams {
+    int thres_method;
+    int block[16];      // per threshold plane: block size (ADPT) (already fixed up to odd >= 3)
+    double p1[16];      // per plane param1 (FIXED uses it as the threshold)
+    int idelta;         // floor(param2)
+    int nthr;           // planes per frame
+    int corner_method;
+    int warp_size;
+    int min_contour, max_contour;   // contour length bounds (exclusive)
+    int bx0, by0, bx1, by1;         // valid region of the border filter [bx0,bx1) x [by0,by1)
+    int subpix_win;
+};
+
+// device pointers + capacities handed to kernels
+struct Buffers {
+    uint8_t* thres;
+    uint8_t* nbr;
+    uint2* trig;
+    ContourDesc* cdesc;
+    short2* pool;
+    Quad* quads;
+    Cand* cands;
+    int32_t* ncands;       // [F]
+    arucohip_marker_t* markers;
+    int32_t* nmarkers;     // [F]
+    uint32_t* counters;
+    uint32_t cap_trig, cap_cdesc, cap_pool;
+    int cap_quads, cap_cands, cap_markers;   // per frame
+};
+
+// ---- kernel launchers (host side, defined in the .hip files)
+void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
+void launch_walkers(hipStream_t s, const FrameGeom& g, const DetectParams& p, const Buffers& b);
+void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
+void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
+void launch_pose(hipStream_t s, int nframes, const CamModel& cam, const Buffers& b);
+void launch_warp_only(hipStream_t s, const uint8_t* gray, const FrameGeom& g, const float* quad_dev, int size, uint8_t* dst_dev);
+void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out);
+void launch_project_points(hipStream_t s, const float* obj, int npts, const double* rt, const CamModel& cam, float* img_out);
+void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const CamModel& cam);
+
+}  // namespace ah

@@ -1,0 +1,442 @@
+// Kernels 2-4 — border following, polygon approximation, quad filtering (detectRectangles).
+//
+// Reference: MarkerDetector::detectRectangles (/root/reference/src/markerdetector.cpp:496-635):
+//   cv::findContours(RETR_LIST, CHAIN_APPROX_NONE) :511, size filter :517, cv::approxPolyDP(eps = 0.05 n) :522,
+//   4 vertices :526, cv::isContourConvex :535, min side :542-552, orientation :566-581, near-duplicates :586-627.
+//
+// cv::findContours is a sequential raster scan that relabels pixels while it follows borders. The point sequence
+// of a border depends only on the binary image, its start pixel and whether it is a hole border, so the scan is
+// replaced by (a) local start candidates from kernel 1 and (b) one walker per candidate that follows the border
+// with OpenCV's step rule and drops itself as soon as it proves it is not the scan's start:
+//   outer border: a visited pixel precedes the start in raster order
+//   hole border : a 4-neighbour background pixel examined during the walk precedes the trigger pixel
+// or as soon as the border is longer than the size filter admits. Survivors are exactly the borders
+// detectRectangles keeps, with the same start and direction.
+#include "internal.h"
+
+namespace ah {
+
+// direction d (0=E,1=NE,2=N,3=NW,4=W,5=SW,6=S,7=SE; y grows downwards) -> pixel step, from packed 2-bit tables
+__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
+
+__device__ __forceinline__ bool raster_lt(int y, int x, int ty, int tx) { return y < ty || (y == ty && x < tx); }
+
+// Initial clockwise search of icvFetchContour: returns direction to the predecessor pixel, or -1 for an isolated pixel.
+__device__ __forceinline__ int first_dir(uint32_t m, int s_end) {
+    int s = s_end;
+    do {
+        s = (s - 1) & 7;
+        if ((m >> s) & 1) break;
+    } while (s != s_end);
+    return s == s_end ? -1 : s;
+}
+
+// One counter-clockwise step: from direction `s` (pointing at the previous pixel) find the next border pixel.
+// Returns the new direction d; *examined = bit mask of the zero neighbours passed over.
+__device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
+    uint32_t mm = m | (m << 8);
+    int sh = (s + 1) & 7;
+    uint32_t rot = (mm >> sh) & 0xFFu;
+    int k = __builtin_ctz(rot | 0x100u);
+    uint32_t ex = (1u << k) - 1u;           // k zero neighbours examined, starting at direction s+1
+    ex = ((ex << sh) | (ex << sh >> 8)) & 0xFFu;
+    *examined = ex;
+    return (sh + k) & 7;
+}
+
+struct WalkArgs {
+    const uint8_t* nbr;
+    const uint2* trig;
+    ContourDesc* cdesc;
+    uint32_t* counters;
+    uint32_t cap_trig, cap_cdesc, cap_pool;
+    int width, height;
+    int min_contour, max_contour;
+};
+
+// Kernel 2: one lane per start candidate.
+__global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
+    const uint32_t ntrig = min(a.counters[CNT_TRIG], a.cap_trig);
+    const int W = a.width;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntrig; i += gridDim.x * blockDim.x) {
+        uint2 t = a.trig[i];
+        const int plane = (int)(t.x >> 1), hole = (int)(t.x & 1);
+        const int tx = (int)(t.y & 0xFFFF), ty = (int)(t.y >> 16);
+        const uint8_t* nb = a.nbr + (size_t)plane * W * a.height;
+        const int x0 = tx - hole, y0 = ty;
+        uint32_t m = nb[(size_t)y0 * W + x0];
+        int s = first_dir(m, hole ? 0 : 4);
+        if (s < 0) continue;  // isolated pixel: 1 point, never passes the size filter
+        const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+        int x = x0, y = y0, n = 0;
+        bool ok = true;
+        for (;;) {
+            uint32_t ex;
+            int d = next_dir(m, s, &ex);
+            if (hole) {
+                // background 4-neighbours examined from (x,y)
+                if (((ex & 1u) && raster_lt(y, x + 1, ty, tx)) || ((ex & 4u) && raster_lt(y - 1, x, ty, tx)) ||
+                    ((ex & 16u) && raster_lt(y, x - 1, ty, tx)) || ((ex & 64u) && raster_lt(y + 1, x, ty, tx))) {
+                    ok = false;
+                    break;
+                }
+            } else if (raster_lt(y, x, y0, x0)) {
+                ok = false;
+                break;
+            }
+            if (++n >= a.max_contour) {
+                ok = false;
+                break;
+            }
+            int nx = x + dir_dx(d), ny = y + dir_dy(d);
+            if (nx == x0 && ny == y0 && x == x1 && y == y1) break;
+            x = nx, y = ny;
+            s = (d + 4) & 7;
+            m = nb[(size_t)y * W + x];
+        }
+        if (!ok || n <= a.min_contour) continue;
+        uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
+        uint32_t off = atomicAdd(&a.counters[CNT_POOL], (uint32_t)n);
+        if (slot >= a.cap_cdesc) {
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+            continue;
+        }
+        if (off + (uint32_t)n > a.cap_pool) {
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
+            n = 0;  // keeps list consistent; a zero-length contour is ignored downstream
+        }
+        ContourDesc cd;
+        cd.plane = plane, cd.x0 = (int16_t)x0, cd.y0 = (int16_t)y0, cd.hole = hole, cd.n = n;
+        cd.key = (uint32_t)ty * (uint32_t)W + (uint32_t)tx;
+        cd.pool_off = off;
+        a.cdesc[slot] = cd;
+    }
+}
+
+void launch_walkers(hipStream_t s, const FrameGeom& g, const DetectParams& p, const Buffers& b) {
+    WalkArgs a;
+    a.nbr = b.nbr, a.trig = b.trig, a.cdesc = b.cdesc, a.counters = b.counters;
+    a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
+    a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
+    // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
+    hipLaunchKernelGGL(walker_kernel, dim3(256 * 16), dim3(64), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 3: one wave per surviving border: emit points, approxPolyDP, convexity, min side -> Quad
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+struct QuadArgs {
+    const uint8_t* nbr;
+    const ContourDesc* cdesc;
+    short2* pool;
+    Quad* quads;
+    uint32_t* counters;
+    uint32_t cap_cdesc;
+    int cap_quads, nthr;
+    int width, height;
+};
+
+__global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
+    extern __shared__ __align__(16) short2 P[];   // contour points
+    __shared__ int s_stack[16][2];
+    __shared__ short2 s_out[12];
+    __shared__ int s_outn;
+    const int lane = threadIdx.x;
+    const uint32_t ncd = min(a.counters[CNT_CDESC], a.cap_cdesc);
+    const int W = a.width;
+    for (uint32_t ci = blockIdx.x; ci < ncd; ci += gridDim.x) {
+        const ContourDesc cd = a.cdesc[ci];
+        const int count = cd.n;
+        __syncthreads();
+        if (count <= 0) continue;
+        // ---- emit the border (same walk as kernel 2, now recording points)
+        if (lane == 0) {
+            const uint8_t* nb = a.nbr + (size_t)cd.plane * W * a.height;
+            int x = cd.x0, y = cd.y0;
+            uint32_t m = nb[(size_t)y * W + x];
+            int s = first_dir(m, cd.hole ? 0 : 4);
+            for (int n = 0; n < count; n++) {
+                uint32_t ex;
+                int d = next_dir(m, s, &ex);
+                P[n] = make_short2((short)x, (short)y);
+                x += dir_dx(d), y += dir_dy(d);
+                s = (d + 4) & 7;
+                m = nb[(size_t)y * W + x];
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < count; i += WAVE) a.pool[cd.pool_off + i] = P[i];
+
+        // ---- cv::approxPolyDP(closed), restated for a wavefront: every "farthest point" scan is a 64-lane argmax with
+        // first-maximum tie break (lowest scan position), control flow is wave-uniform.
+        double eps = (double)count * 0.05;
+        eps *= eps;
+        int pos = 0, rs_start = 0;
+        bool le_eps = false;
+        for (int it = 0; it < 3; it++) {
+            pos = (pos + rs_start) % count;
+            const short2 sp = P[pos];
+            unsigned long long best = 0;
+            for (int j = 1 + lane; j < count; j += WAVE) {
+                int q = pos + j;
+                if (q >= count) q -= count;
+                short2 pt = P[q];
+                int dx = pt.x - sp.x, dy = pt.y - sp.y;
+                unsigned long long key = ((unsigned long long)(uint32_t)(dx * dx + dy * dy) << 32) | (uint32_t)(0x7FFFFFFF - j);
+                best = key > best ? key : best;
+            }
+            best = wave_max_u64(best);
+            uint32_t maxd = (uint32_t)(best >> 32);
+            if (maxd > 0) rs_start = 0x7FFFFFFF - (int)(uint32_t)(best & 0xFFFFFFFFu);
+            le_eps = (double)maxd <= eps;
+        }
+        int top = 0, outn = 0;
+        bool reject = false;
+        if (lane == 0) s_outn = 0;
+        if (!le_eps) {
+            int sl_start = pos % count;
+            int sl_end = (rs_start + sl_start) % count;
+            if (lane == 0) {
+                s_stack[0][0] = sl_end, s_stack[0][1] = sl_start;   // right_slice
+                s_stack[1][0] = sl_start, s_stack[1][1] = sl_end;   // slice
+            }
+            top = 2;
+        } else {
+            if (lane == 0) s_out[0] = P[pos];
+            outn = 1;
+        }
+        __syncthreads();
+        while (top > 0) {
+            if (outn + top > 8) {  // cannot end as 4 vertices (clean-up removes at most every other vertex)
+                reject = true;
+                break;
+            }
+            --top;
+            const int sl_start = s_stack[top][0], sl_end = s_stack[top][1];
+            __syncthreads();
+            const short2 ep = P[sl_end], sp = P[sl_start];
+            int len = sl_end - sl_start;
+            if (len <= 0) len += count;
+            bool small;
+            int split = 0;
+            if (len > 1) {
+                const int dx = ep.x - sp.x, dy = ep.y - sp.y;
+                unsigned long long best = 0;
+                for (int q = lane; q < len - 1; q += WAVE) {
+                    int idx = sl_start + 1 + q;
+                    if (idx >= count) idx -= count;
+                    short2 pt = P[idx];
+                    int cr = (pt.y - sp.y) * dx - (pt.x - sp.x) * dy;
+                    uint32_t ad = (uint32_t)(cr < 0 ? -cr : cr);
+                    unsigned long long key = ((unsigned long long)ad << 32) | (uint32_t)(0x7FFFFFFF - q);
+                    best = key > best ? key : best;
+                }
+                best = wave_max_u64(best);
+                double maxd = (double)(uint32_t)(best >> 32);
+                int q = 0x7FFFFFFF - (int)(uint32_t)(best & 0xFFFFFFFFu);
+                split = sl_start + 1 + q;
+                if (split >= count) split -= count;
+                small = maxd * maxd <= eps * ((double)dx * (double)dx + (double)dy * (double)dy);
+            } else {
+                small = true;
+            }
+            if (small) {
+                if (lane == 0) s_out[outn] = sp;
+                outn++;
+            } else {
+                if (lane == 0) {
+                    s_stack[top][0] = split, s_stack[top][1] = sl_end;
+                    s_stack[top + 1][0] = sl_start, s_stack[top + 1][1] = split;
+                }
+                top += 2;
+            }
+            __syncthreads();
+        }
+        if (reject || outn < 4) continue;
+        // ---- clean-up pass + convexity + min side, lane 0 (<= 8 vertices)
+        if (lane == 0) {
+            int new_count = outn;
+            const int cnt = outn;
+            int p2 = cnt - 1;
+            short2 start_pt = s_out[p2];
+            if (++p2 >= cnt) p2 = 0;
+            int wpos = p2;
+            short2 pt = s_out[p2];
+            if (++p2 >= cnt) p2 = 0;
+            for (int i = 0; i < cnt && new_count > 2; i++) {
+                short2 end_pt = s_out[p2];
+                if (++p2 >= cnt) p2 = 0;
+                double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+                double dist = fabs((double)(pt.x - start_pt.x) * dy - (double)(pt.y - start_pt.y) * dx);
+                double sip = (double)(pt.x - start_pt.x) * (double)(end_pt.x - pt.x) +
+                             (double)(pt.y - start_pt.y) * (double)(end_pt.y - pt.y);
+                if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+                    new_count--;
+                    s_out[wpos] = start_pt = end_pt;
+                    if (++wpos >= cnt) wpos = 0;
+                    pt = s_out[p2];
+                    if (++p2 >= cnt) p2 = 0;
+                    i++;
+                    continue;
+                }
+                s_out[wpos] = start_pt = pt;
+                if (++wpos >= cnt) wpos = 0;
+                pt = end_pt;
+            }
+            bool ok = new_count == 4;
+            if (ok) {  // cv::isContourConvex on 4 int points
+                short2 prev = s_out[2], cur = s_out[3];
+                int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
+                for (int i = 0; i < 4 && ok; i++) {
+                    prev = cur;
+                    cur = s_out[i];
+                    int dx = cur.x - prev.x, dy = cur.y - prev.y;
+                    int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+                    orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+                    if (orientation == 3) ok = false;
+                    dx0 = dx, dy0 = dy;
+                }
+            }
+            if (ok) {  // minimum side > 10 px (intended form of markerdetector.cpp:542-552)
+                int mind2 = 0x7FFFFFFF;
+                for (int j = 0; j < 4; j++) {
+                    int dx = s_out[j].x - s_out[(j + 1) & 3].x, dy = s_out[j].y - s_out[(j + 1) & 3].y;
+                    mind2 = min(mind2, dx * dx + dy * dy);
+                }
+                ok = mind2 > 100;
+            }
+            if (ok) {
+                const int frame = cd.plane / a.nthr, t = cd.plane - frame * a.nthr;
+                uint32_t slot = atomicAdd(&a.counters[CNT_FIXED + frame], 1u);
+                if (slot < (uint32_t)a.cap_quads) {
+                    Quad q;
+                    for (int j = 0; j < 4; j++) q.x[j] = s_out[j].x, q.y[j] = s_out[j].y;
+                    q.cdesc = (int)ci;
+                    q.key = ((uint32_t)t << 26) | (0x3FFFFFFu - cd.key);
+                    q.pad_ = 0;
+                    a.quads[(size_t)frame * a.cap_quads + slot] = q;
+                } else {
+                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_QUAD_OVERFLOW);
+                }
+            }
+        }
+    }
+}
+
+void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+    QuadArgs a;
+    a.nbr = b.nbr, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
+    a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
+    size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(256 * 8), dim3(64), sh, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 4: per frame — reference order, orientation, near-duplicate removal  (markerdetector.cpp:562-627)
+// ---------------------------------------------------------------------------------------------
+struct FrameArgs {
+    const Quad* quads;
+    Cand* cands;
+    int32_t* ncands;
+    uint32_t* counters;
+    int cap_quads, cap_cands;
+};
+
+constexpr int MAXQ = 512;
+
+__device__ __forceinline__ float quad_perimeter_i(const int16_t* x, const int16_t* y) {
+    float sum = 0;
+    for (int i = 0; i < 4; i++) {
+        int j = (i + 1) & 3;
+        double dx = (double)(x[i] - x[j]), dy = (double)(y[i] - y[j]);
+        sum = (float)((double)sum + sqrt(dx * dx + dy * dy));
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
+    __shared__ int16_t sx[MAXQ][4], sy[MAXQ][4];
+    __shared__ int s_cdesc[MAXQ];
+    __shared__ uint8_t s_swapped[MAXQ], s_rem[MAXQ];
+    __shared__ float s_perim[MAXQ];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int nq = min((int)a.counters[CNT_FIXED + frame], min(a.cap_quads, MAXQ));
+    const Quad* Q = a.quads + (size_t)frame * a.cap_quads;
+    // rank by key (keys are unique: one border per scan transition)
+    for (int i = lane; i < nq; i += WAVE) {
+        const uint32_t key = Q[i].key;
+        int rank = 0;
+        for (int j = 0; j < nq; j++) rank += Q[j].key < key;
+        Quad q = Q[i];
+        // orientation: cross((c1-c0),(c2-c0)) < 0 -> swap corners 1 and 3
+        int d1x = q.x[1] - q.x[0], d1y = q.y[1] - q.y[0], d2x = q.x[2] - q.x[0], d2y = q.y[2] - q.y[0];
+        float o = ((float)d1x * (float)d2y) - ((float)d1y * (float)d2x);
+        bool sw = o < 0.0f;
+        if (sw) {
+            int16_t tx = q.x[1], ty = q.y[1];
+            q.x[1] = q.x[3], q.y[1] = q.y[3];
+            q.x[3] = tx, q.y[3] = ty;
+        }
+        for (int k = 0; k < 4; k++) sx[rank][k] = q.x[k], sy[rank][k] = q.y[k];
+        s_cdesc[rank] = q.cdesc;
+        s_swapped[rank] = sw;
+        s_rem[rank] = 0;
+        s_perim[rank] = quad_perimeter_i(q.x, q.y);
+    }
+    __syncthreads();
+    // pairs (i<j) whose four same-index corners are all closer than 6 px: drop the smaller perimeter
+    for (int i = 0; i < nq; i++) {
+        for (int j = i + 1 + lane; j < nq; j += WAVE) {
+            bool near = true;
+            for (int c = 0; c < 4; c++) {
+                int dx = sx[i][c] - sx[j][c], dy = sy[i][c] - sy[j][c];
+                near = near && (dx * dx + dy * dy < 36);
+            }
+            if (near) {
+                if (s_perim[i] > s_perim[j])
+                    s_rem[j] = 1;
+                else
+                    s_rem[i] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int n = 0;
+        Cand* C = a.cands + (size_t)frame * a.cap_cands;
+        for (int i = 0; i < nq; i++) {
+            if (s_rem[i]) continue;
+            if (n >= a.cap_cands) {
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CAND_OVERFLOW);
+                break;
+            }
+            Cand c;
+            for (int k = 0; k < 4; k++) {
+                c.c[2 * k] = (float)sx[i][k], c.c[2 * k + 1] = (float)sy[i][k];
+                c.qx[k] = sx[i][k], c.qy[k] = sy[i][k];
+            }
+            c.cdesc = s_cdesc[i], c.swapped = s_swapped[i], c.id = -1, c.nrot = 0;
+            C[n++] = c;
+        }
+        a.ncands[frame] = n;
+    }
+}
+
+void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+    FrameArgs a;
+    a.quads = b.quads, a.cands = b.cands, a.ncands = b.ncands, a.counters = b.counters;
+    a.cap_quads = b.cap_quads, a.cap_cands = b.cap_cands;
+    hipLaunchKernelGGL(frame_candidates_kernel, dim3(nframes), dim3(64), 0, s, a);
+}
+
+}  // namespace ah

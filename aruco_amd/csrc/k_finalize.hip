@@ -1,0 +1,173 @@
+// Kernels 7-8 — per-frame marker list (sort by id, same-id dedupe, border filter) and batched pose.
+//
+// Reference: MarkerDetector::detect tail (/root/reference/src/markerdetector.cpp:371-382 split valid / rejected,
+// :417 std::sort by id, :421-430 same-id dedupe by perimeter, :433-447 border filter, :450-467 per-marker solvePnP),
+// perimeter (src/utils.h:39-46), getObjectPoints (src/marker.cpp:91-108), rotateXAxis (src/utils.cpp:16-30),
+// BoardDetector pose (src/boarddetector.cpp:157-198).
+#include "internal.h"
+#include "pnp_device.h"
+
+namespace ah {
+
+constexpr int MAXM = 256;
+
+__device__ __forceinline__ float perimeter_f(const float* c) {
+    float sum = 0;
+    for (int i = 0; i < 4; i++) {
+        int j = (i + 1) & 3;
+        float dx = c[2 * i] - c[2 * j], dy = c[2 * i + 1] - c[2 * j + 1];
+        sum = (float)((double)sum + sqrt((double)dx * dx + (double)dy * dy));
+    }
+    return sum;
+}
+
+struct FinalArgs {
+    const Cand* cands;
+    const int32_t* ncands;
+    arucohip_marker_t* markers;
+    int32_t* nmarkers;
+    uint32_t* counters;
+    int cap_cands, cap_markers;
+    int bx0, by0, bx1, by1;
+};
+
+__global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
+    __shared__ int s_src[MAXM];      // candidate index, sorted by (id, candidate order)
+    __shared__ int s_id[MAXM];
+    __shared__ uint8_t s_rem[MAXM];
+    __shared__ int s_nvalid;
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int nc = a.ncands[frame];
+    const Cand* C = a.cands + (size_t)frame * a.cap_cands;
+    // stable rank by id among decoded candidates
+    if (lane == 0) s_nvalid = 0;
+    __syncthreads();
+    for (int i = lane; i < nc; i += WAVE) {
+        int id = C[i].id;
+        if (id < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < nc; j++) {
+            int idj = C[j].id;
+            if (idj < 0) continue;
+            rank += (idj < id) || (idj == id && j < i);
+        }
+        if (rank < MAXM) s_src[rank] = i, s_id[rank] = id, s_rem[rank] = 0;
+        atomicAdd(&s_nvalid, 1);
+    }
+    __syncthreads();
+    const int nv = min(s_nvalid, MAXM);
+    if (lane == 0) {
+        for (int i = 0; i < nv - 1; i++) {
+            if (s_id[i] == s_id[i + 1] && !s_rem[i + 1]) {
+                if (perimeter_f(C[s_src[i]].c) > perimeter_f(C[s_src[i + 1]].c))
+                    s_rem[i + 1] = 1;
+                else
+                    s_rem[i] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nv; i += WAVE) {  // corners outside Rect(size*t, size*(1-t)) -> drop
+        const float* c = C[s_src[i]].c;
+        for (int k = 0; k < 4; k++) {
+            int px = __float2int_rn(c[2 * k]), py = __float2int_rn(c[2 * k + 1]);
+            if (!(a.bx0 <= px && px < a.bx1 && a.by0 <= py && py < a.by1)) s_rem[i] = 1;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int n = 0;
+        arucohip_marker_t* M = a.markers + (size_t)frame * a.cap_markers;
+        for (int i = 0; i < nv; i++) {
+            if (s_rem[i]) continue;
+            if (n < a.cap_markers) {
+                arucohip_marker_t m;
+                m.id = s_id[i];
+                for (int k = 0; k < 8; k++) m.corners[k] = C[s_src[i]].c[k];
+                m.ssize = -1.f, m.has_pose = 0, m.pad_ = 0;
+                for (int k = 0; k < 3; k++) m.rvec[k] = m.tvec[k] = 0;
+                M[n] = m;
+            }
+            n++;
+        }
+        if (n > a.cap_markers) atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_MARKER_OVERFLOW);
+        a.nmarkers[frame] = n;   // required count; the host clamps and reports ARUCOHIP_E_CAPACITY
+    }
+}
+
+void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
+    FinalArgs a;
+    a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters;
+    a.cap_cands = b.cap_cands, a.cap_markers = b.cap_markers;
+    a.bx0 = p.bx0, a.by0 = p.by0, a.bx1 = p.bx1, a.by1 = p.by1;
+    hipLaunchKernelGGL(finalize_kernel, dim3(nframes), dim3(64), 0, s, a);
+}
+
+// one lane per marker: solvePnP on the 4 corners against the marker's own square
+__device__ inline void marker_pose(arucohip_marker_t* m, const CamModel& cam) {
+    float hs = (float)((double)cam.marker_size / 2.);
+    float obj[12] = {-hs, -hs, 0, -hs, hs, 0, hs, hs, 0, hs, -hs, 0};
+    double r[3], t[3];
+    bool ok = solve_pnp_planar(obj, m->corners, 4, cam, r, t);
+    if (ok && cam.y_perp) rotate_x_axis(r);
+    for (int k = 0; k < 3; k++) m->rvec[k] = ok ? r[k] : 0, m->tvec[k] = ok ? t[k] : 0;
+    m->has_pose = ok ? 1 : 0;
+    m->ssize = cam.marker_size;
+}
+
+__global__ __launch_bounds__(64) void pose_kernel(arucohip_marker_t* markers, const int32_t* nmarkers, int cap_markers, int nframes, CamModel cam) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int frame = gid / cap_markers, i = gid - frame * cap_markers;
+    if (frame >= nframes || i >= min(nmarkers[frame], cap_markers)) return;
+    marker_pose(markers + (size_t)frame * cap_markers + i, cam);
+}
+
+void launch_pose(hipStream_t s, int nframes, const CamModel& cam, const Buffers& b) {
+    int total = nframes * b.cap_markers;
+    hipLaunchKernelGGL(pose_kernel, dim3((total + 63) / 64), dim3(64), 0, s, b.markers, b.nmarkers, b.cap_markers, nframes, cam);
+}
+
+__global__ __launch_bounds__(64) void marker_pose_kernel(arucohip_marker_t* markers, int n, CamModel cam) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) marker_pose(markers + i, cam);
+}
+
+void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const CamModel& cam) {
+    hipLaunchKernelGGL(marker_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, markers, n, cam);
+}
+
+// generic planar PnP over npts correspondences (board pose): a single lane, everything in private memory
+__global__ void pnp_points_kernel(const float* obj, const float* img, int npts, CamModel cam, double* rt, int* ok_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    bool ok = solve_pnp_planar(obj, img, npts, cam, r, t);
+    for (int k = 0; k < 3; k++) rt[k] = r[k], rt[3 + k] = t[k];
+    *ok_out = ok ? 1 : 0;
+}
+
+void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out) {
+    hipLaunchKernelGGL(pnp_points_kernel, dim3(1), dim3(64), 0, s, obj, img, npts, cam, rt_out, ok_out);
+}
+
+// cv::projectPoints(obj, rvec, tvec, K, dist) -> float image points (BoardDetector reprojection filter)
+__global__ void project_points_kernel(const float* obj, int npts, const double* rt, CamModel cam, float* img) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    double R[9];
+    rodrigues_vec2mat(rt, R, nullptr);
+    double mx, my;
+    project_point(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], R, nullptr, rt + 3, cam.K, cam.k, &mx, &my, nullptr, nullptr);
+    img[2 * i] = (float)mx, img[2 * i + 1] = (float)my;
+}
+
+void launch_project_points(hipStream_t s, const float* obj, int npts, const double* rt, const CamModel& cam, float* img_out) {
+    hipLaunchKernelGGL(project_points_kernel, dim3((npts + 63) / 64), dim3(64), 0, s, obj, npts, rt, cam, img_out);
+}
+
+// rotateXAxis on a pose stored as rt[0..2]
+__global__ void rotate_x_kernel(double* rt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) rotate_x_axis(rt);
+}
+void launch_rotate_x(hipStream_t s, double* rt) { hipLaunchKernelGGL(rotate_x_kernel, dim3(1), dim3(64), 0, s, rt); }
+
+}  // namespace ah

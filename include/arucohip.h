@@ -1,0 +1,178 @@
+/*
+ * arucohip — C ABI of the MI355X-native ArUco marker-detection hot path.
+ *
+ * This is the drop-in boundary for ONE path of the reference library (paroj/aruco, ArUco 1.3):
+ *   aruco::MarkerDetector::detect()   /root/reference/src/markerdetector.h:102-120, .cpp:302-478
+ *   aruco::BoardDetector::detect()    /root/reference/src/boarddetector.h:103-108, .cpp:90-205
+ * plus the public stage entry points the reference keeps callable (markerdetector.h:255-280).
+ * Everything is plain C: pointers, sizes, PODs. No OpenCV, no torch types. The header-only C++ shim in
+ * include/aruco_hip_shim.hpp rebuilds the reference's classes on top of these calls.
+ *
+ * Threading: like the reference object (markerdetector.cpp:334,372-380 mutate members) a handle is not
+ * re-entrant. One handle owns one HIP stream and all device buffers; use one handle per host thread.
+ */
+#ifndef ARUCOHIP_H
+#define ARUCOHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARUCOHIP_VERSION 100
+
+/* status codes; mirror the reference's failure modes (CV_Assert -> cv::Exception), SURVEY.md §8b "Errors" */
+enum {
+    ARUCOHIP_OK = 0,
+    ARUCOHIP_E_INVALID = 1,      /* bad argument: what the reference rejects with CV_Assert (markerdetector.cpp:644,685,1032-1034,1048) */
+    ARUCOHIP_E_CAPACITY = 2,     /* output array too small; *n_out holds the required count */
+    ARUCOHIP_E_UNSUPPORTED = 3,  /* CANNY threshold, locked corners, user decoder callback: not on this path */
+    ARUCOHIP_E_HIP = 4,          /* HIP runtime failure, see arucohip_last_error_string */
+    ARUCOHIP_E_OVERFLOW = 5,     /* an internal device list overflowed (raise limits with arucohip_create_ex) */
+    ARUCOHIP_E_BOARD_CONFIG = 6  /* empty board configuration (boarddetector.cpp:93) */
+};
+
+/* MarkerDetector::ThresholdMethods (markerdetector.h:125) */
+enum { ARUCOHIP_THRES_FIXED = 0, ARUCOHIP_THRES_ADPT = 1, ARUCOHIP_THRES_CANNY = 2 };
+/* MarkerDetector::CornerRefinementMethod (markerdetector.h:192) */
+enum { ARUCOHIP_CORNER_NONE = 0, ARUCOHIP_CORNER_HARRIS = 1, ARUCOHIP_CORNER_SUBPIX = 2, ARUCOHIP_CORNER_LINES = 3 };
+/* BoardConfiguration::mInfoType (board.h:64) */
+enum { ARUCOHIP_BOARD_NONE = -1, ARUCOHIP_BOARD_PIX = 0, ARUCOHIP_BOARD_METERS = 1 };
+/* decoder behind MarkerDetector::setMakerDetectorFunction (markerdetector.h:243) */
+enum { ARUCOHIP_DECODER_FIDUCIAL_5X5 = 0 };
+
+/* 1:1 image of MarkerDetector's private configuration members (markerdetector.h:283-306; defaults .cpp:235-249). */
+typedef struct arucohip_params {
+    int32_t thres_method;       /* _thresMethod        default ADPT */
+    int32_t thres_param1_range; /* _thresParam1_range  default 0    */
+    double thres_param1;        /* _thresParam1        default 7    */
+    double thres_param2;        /* _thresParam2        default 7    */
+    int32_t corner_method;      /* _cornerMethod       default LINES */
+    int32_t warp_size;          /* _markerWarpSize     default 56 (>= 10, multiple of 7 recommended) */
+    float min_size;             /* _minSize            default 0.04 */
+    float max_size;             /* _maxSize            default 0.5  */
+    float border_dist;          /* _borderDistThres    default 0.025 */
+    int32_t use_locked_corners; /* _useLockedCorners   default 0 (1 -> ARUCOHIP_E_UNSUPPORTED) */
+    int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5 */
+    int32_t reserved_;
+} arucohip_params_t;
+
+/* aruco::Marker (marker.h:46-53): id, 4 corners (x0,y0,..), ssize, Rvec/Tvec as double. 96 bytes. */
+typedef struct arucohip_marker {
+    int32_t id;
+    float corners[8];
+    float ssize;
+    int32_t has_pose;
+    int32_t pad_;
+    double rvec[3];
+    double tvec[3];
+} arucohip_marker_t;
+
+/* aruco::Board pose part (board.h:99-104); the member markers are returned in a caller array. */
+typedef struct arucohip_board {
+    int32_t n_markers;
+    int32_t has_pose;
+    double rvec[3];
+    double tvec[3];
+} arucohip_board_t;
+
+/* device-side limits of one handle */
+typedef struct arucohip_limits {
+    int32_t max_width, max_height;
+    int32_t max_batch;             /* frames per arucohip_detect_batch call */
+    int32_t max_thres_planes;      /* 2*range+1 supported per frame */
+    int32_t triggers_per_frame;    /* border-start candidates (average per frame) */
+    int32_t contours_per_frame;    /* borders that pass the size filter */
+    int32_t points_per_frame;      /* contour-point pool (average per frame) */
+    int32_t candidates_per_frame;  /* quads per frame */
+    int32_t markers_per_frame;     /* device-side marker slots per frame */
+} arucohip_limits_t;
+
+typedef struct arucohip_handle arucohip_handle;
+
+int arucohip_version(void);
+void arucohip_default_params(arucohip_params_t* p);
+void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height, int max_batch);
+
+/* Create a detector on HIP device `device` able to take frames up to max_width x max_height, `max_batch` at a time.
+ * params may be NULL (reference defaults). */
+int arucohip_create(const arucohip_params_t* params, int device, int max_width, int max_height, int max_batch,
+                    arucohip_handle** out);
+int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* limits, arucohip_handle** out);
+void arucohip_destroy(arucohip_handle* h);
+/* setters of MarkerDetector (markerdetector.h:129-245) collapse into one call; validates like setMinMaxSize /
+ * setWarpSize (markerdetector.cpp:1031-1051). */
+int arucohip_set_params(arucohip_handle* h, const arucohip_params_t* p);
+int arucohip_get_params(const arucohip_handle* h, arucohip_params_t* p);
+const char* arucohip_last_error_string(const arucohip_handle* h);
+
+/* Run the handle's work on an existing HIP stream (hipStream_t passed as void*); NULL restores the handle's own. */
+int arucohip_set_stream(arucohip_handle* h, void* hip_stream);
+void* arucohip_get_stream(arucohip_handle* h);
+int arucohip_synchronize(arucohip_handle* h);
+
+/* MarkerDetector::detect (markerdetector.h:102-103) for one 8-bit gray frame in HOST memory.
+ * K: 9 floats row-major or NULL (no pose); dist: ndist (0,4,5,8) floats or NULL; marker_size <= 0 -> no pose.
+ * out/cap: caller array; *n_out = number of markers (sorted by id). */
+int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int width, int height, size_t row_stride, const float* K,
+                    const float* dist, int ndist, float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap,
+                    int* n_out);
+
+/* Same for a batch of nframes equally sized frames (frame f at frames + f*frame_stride).
+ * frames_on_device != 0: `frames` is a device pointer (frames already resident in HBM).
+ * out_on_device   != 0: `out` (nframes*cap markers) and `n_out` (nframes int32) are device pointers, the call is
+ *                       asynchronous on the handle's stream and reports only launch errors; otherwise host arrays and
+ *                       the call returns when the results are there. */
+int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                          size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
+                          float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
+                          int out_on_device);
+/* After an asynchronous batch: synchronise and report device-side overflow / capacity conditions. */
+int arucohip_batch_status(arucohip_handle* h);
+
+/* MarkerDetector::getThresholdedImage (markerdetector.h:183): thresholded image of frame `frame` of the last call
+ * (the middle one when thres_param1_range > 0), copied to host `dst` (width*height bytes, tightly packed). */
+int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst);
+/* MarkerDetector::getCandidates (markerdetector.h:266): quads that were rectangles but not markers. quads: cap*8 floats. */
+int arucohip_get_candidates(arucohip_handle* h, int frame, float* quads, int cap, int* n);
+
+/* Stage entry points the reference keeps public (markerdetector.h:255-280), on host buffers. */
+int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int width, int height, size_t row_stride,
+                       double param1, double param2, uint8_t* dst);
+int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int width, int height, size_t row_stride,
+                               float* quads, int cap, int* n);
+int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int width, int height, size_t row_stride, const float quad[8],
+                  int size, uint8_t* dst);
+
+/* Stage inspection for parity tests (results of the last detect/detect_batch/detect_rectangles call).
+ * Contours that passed the size filter, in the reference's cv::findContours(RETR_LIST) relative order. */
+int arucohip_debug_num_contours(arucohip_handle* h, int frame, int* n);
+int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hole, int* start_x, int* start_y, int16_t* xy,
+                           int cap_points, int* n_points);
+/* Candidates after detectRectangles in reference order: integer quad, decoded id (-1 none), nRotations. */
+int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int32_t* ids, int32_t* nrot, int cap, int* n);
+
+/* BoardDetector::detect (boarddetector.h:103-108). markers: output of arucohip_detect; ids/obj: BoardConfiguration
+ * (board.h:56-69) as nboard ids and nboard*4*3 floats; returns likelihood in *prob (found / total).
+ * out_markers (cap n) receives the board's member markers (Board : vector<Marker>). */
+int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, int n, const int32_t* ids, const float* obj,
+                          int nboard, int info_type, const float* K, const float* dist, int ndist, float marker_size,
+                          float repj_err_thres, int y_perpendicular, arucohip_marker_t* out_markers, arucohip_board_t* out,
+                          float* prob);
+
+/* Marker::calculateExtrinsics (marker.h:98-104 / marker.cpp:112-124) for n markers at once (batched solvePnP). */
+int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers, int n, const float* K, const float* dist,
+                                  int ndist, float marker_size, int y_perpendicular);
+
+/* Per-stage device time of the last batch in milliseconds (hipEvent pairs on the handle's stream), the reference's
+ * ARUCO_MARKER_BENCHMARK stages (markerdetector.cpp:472-476): names via arucohip_stage_name. Returns count. */
+int arucohip_stage_times(arucohip_handle* h, float* ms, int cap);
+const char* arucohip_stage_name(int i);
+int arucohip_enable_timing(arucohip_handle* h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARUCOHIP_H */

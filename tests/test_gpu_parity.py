@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path (through the C ABI, aruco_amd/libarucohip.so) against the CPU oracle on the same
+inputs, and against the reference's golden vectors. Bit-exact for byte / integer / index results (threshold image,
+contour point sequences, quads, ids, rotations, marker order); sub-pixel corners and poses within 1e-4 relative
+(north_star tolerance) — tolerances are written next to each assert.
+"""
+import numpy as np
+import pytest
+
+from tests.util import load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CORNER_REL_TOL = 1e-4   # relative to the coordinate magnitude (north_star: "1e-4 relative")
+POSE_REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch  # noqa: F401  (load torch's HIP runtime first, see aruco_amd/capi.py)
+    from aruco_amd import capi, synth
+    from oracle import orc
+
+    assert torch.cuda.is_available()
+    capi.load()
+    return {"capi": capi, "orc": orc, "synth": synth, "torch": torch}
+
+
+@pytest.fixture(scope="module")
+def handle(env):
+    h = env["capi"].Handle(1920, 1080, max_batch=4)
+    yield h
+    h.close()
+
+
+def blob_image(rng, h, w, scale=6, thr=0.0):
+    """Random smooth blobs -> binary 0/255 image with many nested borders."""
+    a = rng.randn(h // scale + 2, w // scale + 2)
+    a = np.kron(a, np.ones((scale, scale)))[:h, :w]
+    # cheap smoothing
+    for _ in range(2):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5
+    return ((a > thr) * 255).astype(np.uint8)
+
+
+def gray_cases(env):
+    rng = np.random.RandomState(7)
+    cases = [(n, load_case(n)[0]) for n in ("single", "board", "chessboard")]
+    cases.append(("noise_641x479", rng.randint(0, 256, size=(479, 641)).astype(np.uint8)))
+    cases.append(("ramp_100x70", (np.add.outer(np.arange(70) * 3, np.arange(100) * 2) % 256).astype(np.uint8)))
+    fr, _ = env["synth"].make_stream(1, width=1920, height=1080, seed=11, device="cuda")
+    cases.append(("synth1080", fr[0].cpu().numpy()))
+    return cases
+
+
+def test_threshold_bit_exact(env, handle):
+    capi, orc = env["capi"], env["orc"]
+    for name, g in gray_cases(env):
+        for block, c in ((7, 7.0), (3, 2.0), (21, 7.0), (9, -3.5)):
+            got = handle.threshold(g, capi.THRES_ADPT, block, c)
+            exp = orc.adaptive_threshold(g, block, c)
+            assert np.array_equal(got, exp), (name, block, c, int((got != exp).sum()))
+        got = handle.threshold(g, capi.THRES_FIXED, 100.0, 0.0)
+        assert np.array_equal(got, np.where(g > 100, 0, 255).astype(np.uint8)), name
+
+
+def _contour_check(env, handle, gray_or_bin, binary, min_size, max_size=0.5):
+    capi, orc = env["capi"], env["orc"]
+    p = handle.get_params()
+    saved = (p.min_size, p.max_size)
+    p.min_size, p.max_size = min_size, max_size
+    handle.set_params(p)
+    try:
+        hgt, wid = gray_or_bin.shape
+        if binary:
+            handle.detect_rectangles(gray_or_bin)
+            ref = orc.find_contours(gray_or_bin)
+        else:
+            handle.detect(gray_or_bin)
+            ref = orc.find_contours(orc.adaptive_threshold(gray_or_bin, 7, 7.0))
+        lo = int(np.float32(min_size) * np.float32(max(wid, hgt)) * np.float32(4))
+        hi = int(np.float32(max_size) * np.float32(max(wid, hgt)) * np.float32(4))
+        ref = [c for c in ref if lo < len(c["pts"]) < hi]
+        got = handle.debug_contours(0)
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert a["hole"] == b["hole"]
+            assert np.array_equal(a["pts"], b["pts"])   # same start pixel, same direction, every point
+        return len(ref)
+    finally:
+        p.min_size, p.max_size = saved
+        handle.set_params(p)
+
+
+def test_contours_exact_on_blobs(env, handle):
+    """Border following equals cv::findContours' scan on dense random blob images (nested holes, thin bridges)."""
+    rng = np.random.RandomState(3)
+    total = 0
+    for (h, w, scale) in ((240, 320, 6), (479, 641, 4), (300, 300, 3), (200, 520, 10), (128, 128, 2)):
+        img = blob_image(rng, h, w, scale)
+        total += _contour_check(env, handle, img, True, 0.004, 1.0)
+    # pure salt-and-pepper: single pixels, diagonal chains, 1-px lines
+    img = ((rng.rand(160, 200) > 0.55) * 255).astype(np.uint8)
+    total += _contour_check(env, handle, img, True, 0.002, 1.0)
+    assert total > 200
+
+
+def test_contours_exact_on_frames(env, handle):
+    for name, g in gray_cases(env):
+        if min(g.shape) < 100:
+            continue
+        _contour_check(env, handle, g, False, 0.01)
+
+
+def _compare_markers(got, exp, corner_tol=CORNER_REL_TOL, pose=False):
+    assert [int(m["id"]) for m in got] == [m["id"] for m in exp]
+    for a, b in zip(got, exp):
+        ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+        assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < corner_tol
+        if pose:
+            assert int(a["has_pose"]) == 1
+            assert rel_err(a["rvec"], b["rvec"]) < POSE_REL_TOL
+            assert rel_err(a["tvec"], b["tvec"]) < POSE_REL_TOL
+
+
+def test_candidates_and_decode_exact(env, handle):
+    orc = env["orc"]
+    for name, g in gray_cases(env):
+        if min(g.shape) < 100:
+            continue
+        o = orc.Oracle()
+        o.detect(g)
+        handle.detect(g)
+        q, ids, nrot = handle.debug_candidates(0)
+        ref = o.candidates()
+        assert len(q) == len(ref), name
+        for i, r in enumerate(ref):
+            assert np.array_equal(q[i], r["quad0"]), (name, i)     # integer quads, reference order
+            assert ids[i] == r["id"], (name, i)
+            if r["id"] >= 0:
+                assert nrot[i] == r["nrot"], (name, i)
+        rej = handle.candidates(0)
+        assert len(rej) == len(o.rejected())
+        assert np.array_equal(handle.thresholded(0, g.shape), o.thresholded())
+
+
+def test_warp_bit_exact(env, handle):
+    orc = env["orc"]
+    g, _ = load_case("board")
+    o = orc.Oracle()
+    o.detect(g)
+    for c in o.candidates():
+        for size in (56, 28):
+            assert np.array_equal(handle.warp(g, c["quad0"], size), orc.warp(g, c["quad0"], size))
+
+
+def test_golden_single(env, handle):
+    """Reference test Aruco.Single (test/core_tests.cpp:77-116) through the HIP path."""
+    g, doc = load_case("single")
+    intr = doc["intrinsics"]
+    got = handle.detect(g, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    exp = [{"id": e["id"], "corners": e["corners"], "rvec": e["Rvec"], "tvec": e["Tvec"]} for e in doc["markers"]]
+    _compare_markers(got, exp, pose=True)
+    ref = env["orc"].Oracle().detect(g, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    _compare_markers(got, ref, corner_tol=1e-6, pose=True)
+
+
+@pytest.mark.parametrize("name", ["board", "chessboard"])
+def test_golden_boards(env, handle, name):
+    """Reference tests Aruco.Board / Aruco.Multi (test/core_tests.cpp:164-228) through the HIP path."""
+    capi, orc = env["capi"], env["orc"]
+    g, doc = load_case(name)
+    intr, bc = doc["intrinsics"], doc["board_conf"]
+    got = handle.detect(g)
+    b = handle.board_detect(got, bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0)
+    _compare_markers(b["markers"], doc["markers"])
+    assert rel_err(b["rvec"], doc["board"]["Rvec"]) < POSE_REL_TOL
+    assert rel_err(b["tvec"], doc["board"]["Tvec"]) < POSE_REL_TOL
+    assert abs(b["prob"] - len(doc["markers"]) / len(bc["ids"])) < 1e-6
+    ob = orc.board_detect(orc.Oracle().detect(g), bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0)
+    assert rel_err(b["rvec"], ob["rvec"]) < 1e-6 and rel_err(b["tvec"], ob["tvec"]) < 1e-6
+    # reprojection-error filter + y-perpendicular variant (aruco_test_board configuration)
+    b2 = handle.board_detect(got, bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0, repj_err_thres=1.5, y_perp=True)
+    o2 = orc.board_detect(orc.Oracle().detect(g), bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0, 1.5, True)
+    assert rel_err(b2["rvec"], o2["rvec"]) < POSE_REL_TOL and rel_err(b2["tvec"], o2["tvec"]) < POSE_REL_TOL
+
+
+@pytest.mark.parametrize("method", ["NONE", "HARRIS", "SUBPIX", "LINES"])
+def test_corner_methods_vs_oracle(env, handle, method):
+    capi, orc = env["capi"], env["orc"]
+    code = {"NONE": 0, "HARRIS": 1, "SUBPIX": 2, "LINES": 3}[method]
+    p = handle.get_params()
+    saved = p.corner_method
+    p.corner_method = code
+    handle.set_params(p)
+    try:
+        for name in ("single", "board"):
+            g, doc = load_case(name)
+            intr = doc["intrinsics"]
+            got = handle.detect(g, K=intr["K"], dist=intr["dist"], marker_size=0.05, y_perp=(name == "board"))
+            ref = orc.Oracle(corner_method=code).detect(g, K=intr["K"], dist=intr["dist"], marker_size=0.05, y_perp=(name == "board"))
+            _compare_markers(got, ref, pose=True)
+    finally:
+        p.corner_method = saved
+        handle.set_params(p)
+
+
+def test_synthetic_1080p_batch(env, handle):
+    """Config 2/3 frames: batch == per-frame == oracle; detected ids are the rendered ids, corners within 1 px of truth."""
+    orc, synth = env["orc"], env["synth"]
+    fr, truth = synth.make_stream(3, seed=4711, device="cuda")
+    frames = fr.cpu().numpy()
+    K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1]
+    dist = [-0.10, 0.02, 1e-3, -5e-4, 0]
+    batch = handle.detect_batch_host(frames, K=K, dist=dist, marker_size=0.05)
+    o = orc.Oracle()
+    for f in range(len(frames)):
+        ref = o.detect(frames[f], K=K, dist=dist, marker_size=0.05)
+        _compare_markers(batch[f], ref, pose=True)
+        single = handle.detect(frames[f], K=K, dist=dist, marker_size=0.05)
+        assert single.tobytes() == batch[f].tobytes()
+        tq = {t["id"]: t["quad"] for t in truth[f]}
+        assert set(int(m["id"]) for m in batch[f]) <= set(tq)
+        assert len(batch[f]) >= len(tq) - 1
+        for m in batch[f]:
+            c = np.asarray(m["corners"], float).reshape(4, 2)
+            q = tq[int(m["id"])]
+            assert min(np.max(np.linalg.norm(np.roll(q, k, axis=0) - c, axis=1)) for k in range(4)) < 1.5
+
+
+def test_device_resident_batch(env, handle):
+    """Frames and results stay in HBM (torch tensors by raw pointer), the path bench.py times."""
+    torch, synth, capi = env["torch"], env["synth"], env["capi"]
+    fr, _ = synth.make_stream(2, seed=5, device="cuda")
+    cap = 64
+    out = torch.zeros((2, cap * 96), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    handle.detect_batch_device(fr.data_ptr(), 2, 1920, 1080, out.data_ptr(), cap, n.data_ptr())
+    handle.batch_status()
+    host = handle.detect_batch_host(fr.cpu().numpy())
+    nn = n.cpu().numpy()
+    arr = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(2, cap)
+    for f in range(2):
+        assert nn[f] == len(host[f])
+        assert arr[f, :nn[f]].tobytes() == host[f].tobytes()
+
+
+def test_error_codes(env, handle):
+    capi = env["capi"]
+    p = handle.get_params()
+    p.min_size, p.max_size = 0.6, 0.5
+    with pytest.raises(capi.ArucoHipError) as e:
+        handle.set_params(p)
+    assert e.value.code == capi.E_INVALID
+    p = handle.get_params()
+    p.warp_size = 5
+    with pytest.raises(capi.ArucoHipError):
+        handle.set_params(p)
+    p = handle.get_params()
+    p.thres_method = capi.THRES_CANNY
+    with pytest.raises(capi.ArucoHipError) as e:
+        handle.set_params(p)
+    assert e.value.code == capi.E_UNSUPPORTED
+    g, _ = load_case("board")
+    with pytest.raises(capi.ArucoHipError) as e:
+        handle.detect(g, cap=3)
+    assert e.value.code == capi.E_CAPACITY
+    with pytest.raises(capi.ArucoHipError) as e:
+        handle.board_detect(handle.detect(g), [], np.zeros((0, 4, 3)), 0, None, None, 1.0)
+    assert e.value.code == capi.E_BOARD_CONFIG
