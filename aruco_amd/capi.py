@@ -62,7 +62,8 @@ SYMBOLS = [
     "arucohip_get_thresholded", "arucohip_get_candidates", "arucohip_threshold", "arucohip_detect_rectangles",
     "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
-    "arucohip_enable_timing",
+    "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
+    "arucohip_debug_counters",
 ]
 
 _lib = None
@@ -86,6 +87,7 @@ def load():
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     L.arucohip_last_error_string.restype = C.c_char_p
     L.arucohip_stage_name.restype = C.c_char_p
+    L.arucohip_kernel_name.restype = C.c_char_p
     L.arucohip_get_stream.restype = C.c_void_p
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.arucohip_create.argtypes = [vp, i, i, i, i, vp]
@@ -113,6 +115,9 @@ def load():
     L.arucohip_stage_times.argtypes = [vp, vp, i]
     L.arucohip_stage_name.argtypes = [i]
     L.arucohip_enable_timing.argtypes = [vp, i]
+    L.arucohip_kernel_times.argtypes = [vp, vp, i]
+    L.arucohip_kernel_name.argtypes = [i]
+    L.arucohip_debug_counters.argtypes = [vp, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -301,3 +306,13 @@ class Handle:
         ms = (C.c_float * 8)()
         n = self.L.arucohip_stage_times(self.h, ms, 8)
         return {self.L.arucohip_stage_name(i).decode(): ms[i] for i in range(n)}
+
+    def kernel_times(self):
+        ms = (C.c_float * 16)()
+        n = self.L.arucohip_kernel_times(self.h, ms, 16)
+        return {self.L.arucohip_kernel_name(i).decode(): ms[i] for i in range(n)}
+
+    def debug_counters(self):
+        c = np.zeros(8, np.uint32)
+        self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
+        return {"triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}

@@ -23,6 +23,13 @@ using namespace ah;
 
 enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_COUNT };
 static const char* kStageNames[STAGE_COUNT] = {"Threshold", "Rectangles", "Identify", "Subpixel", "Filtering"};
+// one event after every kernel of a batch; a ring of TSETS batches so that asynchronous steps can be averaged
+enum { K_THRESHOLD = 0, K_WALKERS, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
+                                            "decode_kernel", "refine_lines_kernel", "refine_pixels_kernel", "finalize_kernel", "pose_kernel"};
+static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_IDENTIFY,
+                                          STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_FILTERING};
+constexpr int TSETS = 32;
 
 struct arucohip_handle {
     int device = 0;
@@ -46,8 +53,9 @@ struct arucohip_handle {
     const uint8_t* last_gray = nullptr;
     FrameGeom last_geom{};
     bool timing = false;
-    hipEvent_t ev[STAGE_COUNT + 1] = {};
-    float stage_ms[STAGE_COUNT] = {};
+    hipEvent_t ev[TSETS][K_COUNT + 1] = {};
+    int tsets = 0;                       // batches recorded since the last reset
+    float kernel_ms[K_COUNT] = {};       // averages over the recorded batches
     std::string err;
 };
 
@@ -113,14 +121,15 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
 
 static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
-    hipFree(h->buf.thres), hipFree(h->buf.nbr), hipFree(h->buf.trig), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.nbr), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
-    for (auto& e : h->ev)
-        if (e) hipEventDestroy(e);
+    for (auto& set : h->ev)
+        for (auto& e : set)
+            if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
 }
 
@@ -154,7 +163,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     h->stream = h->own_stream;
     const size_t F = lim->max_batch, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
-    b.cap_trig = (uint32_t)std::min<size_t>(P * lim->triggers_per_frame, 0xFFFFFFF0u);
+    b.cap_trig = (uint32_t)lim->triggers_per_frame;
     b.cap_cdesc = (uint32_t)std::min<size_t>(P * lim->contours_per_frame, 0xFFFFFFF0u);
     b.cap_pool = (uint32_t)std::min<size_t>(P * lim->points_per_frame, 0xFFFFFFF0u);
     b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);
@@ -163,7 +172,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
     ALLOC(b.nbr, P * px);
-    ALLOC(b.trig, (size_t)b.cap_trig * sizeof(uint2));
+    ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
+    ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.cdesc, (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, (size_t)b.cap_pool * sizeof(short2));
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
@@ -180,8 +190,9 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if ((e = hipHostMalloc((void**)&h->h_markers, F * b.cap_markers * sizeof(arucohip_marker_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc((void**)&h->h_n, F * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc((void**)&h->h_counters, (CNT_FIXED + F) * sizeof(uint32_t))) != hipSuccess) return bail(e);
-    for (auto& ev : h->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
+    for (auto& set : h->ev)
+        for (auto& ev : set)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
     *out = h;
     return ARUCOHIP_OK;
 }
@@ -234,13 +245,38 @@ int arucohip_synchronize(arucohip_handle* h) {
 int arucohip_enable_timing(arucohip_handle* h, int on) {
     if (!h) return ARUCOHIP_E_INVALID;
     h->timing = on != 0;
+    h->tsets = 0;
     return ARUCOHIP_OK;
+}
+// synchronises the stream and averages the per-kernel event intervals of the batches since enable/reset
+static void collect_times(arucohip_handle* h) {
+    for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] = 0;
+    int n = std::min(h->tsets, TSETS);
+    if (n <= 0) return;
+    hipSetDevice(h->device);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return;
+    for (int s = 0; s < n; s++)
+        for (int k = 0; k < K_COUNT; k++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->ev[s][k], h->ev[s][k + 1]) == hipSuccess) h->kernel_ms[k] += ms;
+        }
+    for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] /= n;
 }
 const char* arucohip_stage_name(int i) { return (i >= 0 && i < STAGE_COUNT) ? kStageNames[i] : ""; }
 int arucohip_stage_times(arucohip_handle* h, float* ms, int cap) {
     if (!h) return 0;
-    for (int i = 0; i < STAGE_COUNT && i < cap; i++) ms[i] = h->stage_ms[i];
+    collect_times(h);
+    for (int i = 0; i < STAGE_COUNT && i < cap; i++) ms[i] = 0;
+    for (int k = 0; k < K_COUNT; k++)
+        if (kKernelStage[k] < cap) ms[kKernelStage[k]] += h->kernel_ms[k];
     return STAGE_COUNT;
+}
+const char* arucohip_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
+int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap) {
+    if (!h) return 0;
+    collect_times(h);
+    for (int i = 0; i < K_COUNT && i < cap; i++) ms[i] = h->kernel_ms[i];
+    return K_COUNT;
 }
 
 }  // extern "C"
@@ -307,7 +343,7 @@ static int check_status(arucohip_handle* h, uint32_t st) {
 
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
-    launch_walkers(h->stream, g, dp, h->buf);
+    launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
     launch_contour_quads(h->stream, g, nframes, dp, h->buf);
     launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
 }
@@ -316,20 +352,32 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     hipStream_t s = h->stream;
     Buffers& b = h->buf;
     HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
-    if (h->timing) hipEventRecord(h->ev[0], s);
+    HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
+    hipEvent_t* ev = h->ev[h->tsets % TSETS];
+    const bool tm = h->timing;
+#define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
+    MARK(0);
     launch_threshold(s, gray_dev, g, nframes, dp, b);
-    if (h->timing) hipEventRecord(h->ev[1], s);
-    run_rectangles(h, g, nframes, dp);
-    if (h->timing) hipEventRecord(h->ev[2], s);
+    MARK(1);
+    launch_walkers(s, g, nframes * dp.nthr, dp, b);
+    MARK(2);
+    launch_contour_quads(s, g, nframes, dp, b);
+    MARK(3);
+    launch_frame_candidates(s, g, nframes, dp, b);
+    MARK(4);
     launch_decode(s, gray_dev, g, nframes, dp, b);
+    MARK(5);
     launch_refine_lines(s, g, nframes, dp, cam, b);
-    if (h->timing) hipEventRecord(h->ev[3], s);
+    MARK(6);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX)
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
-    if (h->timing) hipEventRecord(h->ev[4], s);
+    MARK(7);
     launch_finalize(s, g, nframes, dp, cam, b);
+    MARK(8);
     if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
-    if (h->timing) hipEventRecord(h->ev[5], s);
+    MARK(9);
+#undef MARK
+    if (tm) h->tsets++;
     HIPCHK(h, hipGetLastError());
     h->last_w = g.width, h->last_h = g.height, h->last_frames = nframes, h->last_nthr = dp.nthr;
     h->last_gray = gray_dev, h->last_geom = g;
@@ -396,8 +444,6 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
     HIPCHK(h, hipMemcpyAsync(h->h_n, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->timing)
-        for (int i = 0; i < STAGE_COUNT; i++) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
     int ret = check_status(h, h->h_counters[CNT_STATUS] & ~(uint32_t)ST_MARKER_OVERFLOW);
     for (int f = 0; f < nframes; f++) {
         int n = h->h_n[f];
@@ -417,8 +463,6 @@ int arucohip_batch_status(arucohip_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->h_counters, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->timing)
-        for (int i = 0; i < STAGE_COUNT; i++) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
     return check_status(h, h->h_counters[CNT_STATUS]);
 }
 
@@ -536,6 +580,20 @@ int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hol
     return ARUCOHIP_OK;
 }
 
+int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
+    if (!h || !out8) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out8, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    int planes = std::max(h->last_frames * h->last_nthr, 1);
+    std::vector<uint32_t> tc((size_t)planes * TRIG_CNT_STRIDE);
+    HIPCHK(h, hipMemcpyAsync(tc.data(), h->buf.trig_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint64_t tot = 0;
+    for (int p = 0; p < planes; p++) tot += tc[(size_t)p * TRIG_CNT_STRIDE];
+    out8[0] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFu);
+    return ARUCOHIP_OK;
+}
+
 // ---- stage entry points (markerdetector.h:255-280)
 int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int W, int H, size_t row_stride, double param1, double param2, uint8_t* dst) {
     if (!h || !gray || !dst) return ARUCOHIP_E_INVALID;
@@ -558,6 +616,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     FrameGeom g;
     if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &gray_dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
@@ -581,6 +640,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     FrameGeom g;
     if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     launch_binary_planes(h->stream, dev, g, 1, h->buf);
     run_rectangles(h, g, 1, dp);
     HIPCHK(h, hipGetLastError());

@@ -19,9 +19,10 @@
 namespace ah {
 
 constexpr int WAVE = 64;
+constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters
 
 enum Counter {
-    CNT_TRIG = 0,      // number of entries in trig list
+    CNT_UNUSED0 = 0,
     CNT_CDESC = 1,     // number of contour descriptors
     CNT_POOL = 2,      // contour points allocated
     CNT_STATUS = 3,    // overflow bit flags
@@ -92,7 +93,8 @@ struct DetectParams {
 struct Buffers {
     uint8_t* thres;
     uint8_t* nbr;
-    uint2* trig;
+    uint2* trig;           // [P][cap_trig] border-start candidates per plane
+    uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE] fill level of each plane's list (one counter per 128-byte line)
     ContourDesc* cdesc;
     short2* pool;
     Quad* quads;
@@ -101,14 +103,15 @@ struct Buffers {
     arucohip_marker_t* markers;
     int32_t* nmarkers;     // [F]
     uint32_t* counters;
-    uint32_t cap_trig, cap_cdesc, cap_pool;
+    uint32_t cap_trig;     // per plane
+    uint32_t cap_cdesc, cap_pool;
     int cap_quads, cap_cands, cap_markers;   // per frame
 };
 
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
-void launch_walkers(hipStream_t s, const FrameGeom& g, const DetectParams& p, const Buffers& b);
+void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

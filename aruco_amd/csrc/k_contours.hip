@@ -48,6 +48,7 @@ __device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
 struct WalkArgs {
     const uint8_t* nbr;
     const uint2* trig;
+    const uint32_t* trig_cnt;
     ContourDesc* cdesc;
     uint32_t* counters;
     uint32_t cap_trig, cap_cdesc, cap_pool;
@@ -55,13 +56,14 @@ struct WalkArgs {
     int min_contour, max_contour;
 };
 
-// Kernel 2: one lane per start candidate.
+// Kernel 2: one lane per start candidate; blockIdx.y = plane.
 __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
-    const uint32_t ntrig = min(a.counters[CNT_TRIG], a.cap_trig);
+    const int plane = blockIdx.y;
+    const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE], a.cap_trig);
     const int W = a.width;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntrig; i += gridDim.x * blockDim.x) {
-        uint2 t = a.trig[i];
-        const int plane = (int)(t.x >> 1), hole = (int)(t.x & 1);
+        uint2 t = a.trig[(size_t)plane * a.cap_trig + i];
+        const int hole = (int)(t.x & 1);
         const int tx = (int)(t.y & 0xFFFF), ty = (int)(t.y >> 16);
         const uint8_t* nb = a.nbr + (size_t)plane * W * a.height;
         const int x0 = tx - hole, y0 = ty;
@@ -114,13 +116,13 @@ __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
     }
 }
 
-void launch_walkers(hipStream_t s, const FrameGeom& g, const DetectParams& p, const Buffers& b) {
+void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
     WalkArgs a;
-    a.nbr = b.nbr, a.trig = b.trig, a.cdesc = b.cdesc, a.counters = b.counters;
+    a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
-    hipLaunchKernelGGL(walker_kernel, dim3(256 * 16), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(walker_kernel, dim3(16, nplanes), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,9 +5,13 @@
 // Per 64x32 output tile a 256-thread workgroup stages the gray tile (+halo) in LDS, forms the separable integer
 // box sum, rounds the mean exactly like the u8 box filter, thresholds, and from the binary tile (1-px frame zeroed,
 // as findContours does) derives for every pixel the 8-neighbour occupancy byte and the two local start rules:
-//   outer border start : pixel set,  W, NW, N, NE clear      (raster-first pixel of an 8-connected component)
-//   hole  border start : pixel clear, W and N set             (raster-first pixel of a 4-connected background hole)
-// Candidates are verified by the walkers (k_contours.hip). HBM traffic: read W*H, write 2*W*H (+ sparse list).
+//   outer border start : first pixel of a horizontal run of set pixels with no set pixel 8-adjacent in the row above
+//                        (the raster-first pixel of an 8-connected component is such a pixel)
+//   hole  border start : first pixel of a horizontal run of clear pixels whose left neighbour is set and which has no
+//                        clear pixel directly above (the raster-first pixel of a 4-connected background hole is such)
+// Runs are followed inside the LDS tile only (a run leaving the tile keeps its candidate). Candidates are verified by
+// the walkers (k_contours.hip). Each workgroup collects its candidates in LDS and reserves list space with one atomic
+// on its plane's counter. HBM traffic: read W*H, write 2*W*H (+ sparse list).
 #include "internal.h"
 
 namespace ah {
@@ -28,9 +32,12 @@ struct ThrArgs {
     uint8_t* thres;
     uint8_t* nbr;
     uint2* trig;
+    uint32_t* trig_cnt;
     uint32_t* counters;
     uint32_t cap_trig;
 };
+
+constexpr int LOCAL_TRIG = 192;   // candidates a workgroup can stage in LDS; more go straight to the global list
 
 template <int RT, int MODE>
 __global__ __launch_bounds__(NT) void threshold_kernel(ThrArgs a) {
@@ -44,6 +51,9 @@ __global__ __launch_bounds__(NT) void threshold_kernel(ThrArgs a) {
     uint16_t* hs = (uint16_t*)(lds + ((GP * GH + 15) & ~15));
     uint8_t* bn = (uint8_t*)(hs + ((HP * GH + 7) & ~7));   // (TH+2) x (TW+2), pitch BP
     const int BP = TW + 4;
+    __shared__ uint32_t s_trig[LOCAL_TRIG];
+    __shared__ uint32_t s_ntrig, s_base;
+    if (threadIdx.x == 0) s_ntrig = 0;
 
     const int tid = threadIdx.x;
     const int frame = blockIdx.z;
@@ -139,12 +149,37 @@ __global__ __launch_bounds__(NT) void threshold_kernel(ThrArgs a) {
                 int inside = (x >= 1) & (x <= W - 2) & (y >= 1) & (y <= H - 2);
                 int outer = b & !(w | nw | n | ne);
                 int hole = (!b) & inside & w & n;
+                if (outer) {
+                    // follow the run to the right: any set pixel 8-adjacent in the row above joins an earlier pixel
+                    for (int j = 1; c + 1 + j + 1 <= TW + 1; j++) {
+                        if (!(p[j] & 1)) break;
+                        if (p[-BP + j + 1] & 1) {
+                            outer = 0;
+                            break;
+                        }
+                    }
+                } else if (hole) {
+                    // follow the background run: a clear pixel directly above joins an earlier background pixel
+                    for (int j = 1; c + 1 + j <= TW + 1; j++) {
+                        if (p[j] & 1) break;
+                        if (!(p[-BP + j] & 1)) {
+                            hole = 0;
+                            break;
+                        }
+                    }
+                }
                 if (outer | hole) {
-                    uint32_t slot = atomicAdd(&a.counters[CNT_TRIG], 1u);
-                    if (slot < a.cap_trig)
-                        a.trig[slot] = make_uint2(((uint32_t)plane << 1) | (uint32_t)hole, ((uint32_t)y << 16) | (uint32_t)x);
-                    else
-                        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    uint32_t e = ((uint32_t)hole << 31) | ((uint32_t)y << 16) | (uint32_t)x;
+                    uint32_t ls = atomicAdd(&s_ntrig, 1u);
+                    if (ls < LOCAL_TRIG) {
+                        s_trig[ls] = e;
+                    } else {
+                        uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], 1u);
+                        if (slot < a.cap_trig)
+                            a.trig[(size_t)plane * a.cap_trig + slot] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+                        else
+                            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    }
                 }
             }
         }
@@ -159,6 +194,20 @@ __global__ __launch_bounds__(NT) void threshold_kernel(ThrArgs a) {
                 ndst[off + q] = (uint8_t)(npack >> (8 * q));
             }
         }
+    }
+    // ---- flush the staged start candidates: one atomic per workgroup on the plane's own counter
+    __syncthreads();
+    const uint32_t nl = min(s_ntrig, (uint32_t)LOCAL_TRIG);
+    if (nl == 0) return;
+    if (tid == 0) s_base = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], nl);
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t i = tid; i < nl; i += NT) {
+        uint32_t e = s_trig[i];
+        if (base + i < a.cap_trig)
+            a.trig[(size_t)plane * a.cap_trig + base + i] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+        else
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
     }
 }
 
@@ -187,7 +236,7 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
         ThrArgs a;
         a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
         a.width = g.width, a.height = g.height, a.nthr = p.nthr, a.t = t;
-        a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.counters = b.counters, a.cap_trig = b.cap_trig;
+        a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
         if (p.thres_method == ARUCOHIP_THRES_FIXED) {
             a.R = 0, a.idelta = (int)floor(p.p1[t]), a.magic = 0, a.n_half = 0;
             launch_mode<MODE_FIXED>(s, a, grid);
@@ -206,7 +255,7 @@ void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeo
     ThrArgs a;
     a.gray = thres_in, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
     a.width = g.width, a.height = g.height, a.nthr = 1, a.t = 0;
-    a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.counters = b.counters, a.cap_trig = b.cap_trig;
+    a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
     a.R = 0, a.idelta = 0, a.magic = 0, a.n_half = 0;
     launch_mode<MODE_BINARY>(s, a, grid);
 }

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s at 1920x1080 of the MarkerDetector::detect hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one arucohip_detect_batch over `--batch` synthetic 1080p frames (config 2 of BASELINE.json: ~20 markers
+per frame, threshold + contours + decode + LINES refinement, no pose) that are already resident in HBM; results stay
+in HBM. With N > 1 every rank owns its own camera stream (seed 4711 + rank, frames sharded one stream per GPU, no
+data-path collective) and the per-frame marker blocks are gathered to rank 0 over RCCL once per step (config 5).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+ALG_BYTES_PER_FRAME = 3 * W * H          # gray read + threshold write + threshold read
+HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CAP = 64                                 # marker slots per frame in the gathered block (config 5)
+
+
+def cpu_baseline(frames_host, seconds_single=8.0, seconds_multi=12.0):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port") timed on this box's host cores on a
+    bounded sample of the same frames: single thread, then one detector per core over frames (perf_tests.cpp style:
+    gray input, wall-clock mean)."""
+    import concurrent.futures as cf
+
+    from oracle import orc
+
+    n = len(frames_host)
+    o = orc.Oracle()
+    o.detect_raw(frames_host[0])
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < seconds_single:
+        o.detect_raw(frames_host[done % n])
+        done += 1
+    single = done / (time.perf_counter() - t0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    oracles = [orc.Oracle() for _ in range(cores)]
+    per_thread = max(2, int(single * seconds_multi))
+
+    def work(i):
+        k = 0
+        for j in range(per_thread):
+            oracles[i].detect_raw(frames_host[(i * per_thread + j) % n])
+            k += 1
+        return k
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    multi = total / (time.perf_counter() - t0)
+    return {"value": round(multi, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d + %d detect() calls of the CPU restatement (oracle/) on %d of the bench's 1080p frames, "
+                      "1 thread then %d threads over frames" % (done, total, n, cores),
+            "single_thread_fps": round(single, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
+    ap.add_argument("--frames", type=int, default=256, help="distinct synthetic frames per GPU (SURVEY: up to 1024)")
+    ap.add_argument("--pose", action="store_true", help="config 3: intrinsics + per-marker solvePnP")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from aruco_amd import capi, synth
+    from aruco_amd import dist as adist
+
+    capi.load()
+    B = min(args.batch, args.frames)
+    frames, truth = synth.make_stream(args.frames, width=W, height=H, seed=4711 + rank, device=dev)
+    handle = capi.Handle(W, H, max_batch=B, device=local_rank)
+    stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream shared by the library, its events and RCCL
+    torch.cuda.set_stream(stream)
+    handle.set_stream(stream.cuda_stream)
+    out = torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1] if args.pose else None
+    dcoef = [-0.10, 0.02, 1e-3, -5e-4, 0] if args.pose else None
+    msize = 0.05 if args.pose else -1.0
+    nwin = max(args.frames // B, 1)
+
+    def step(i):
+        off = (i % nwin) * B
+        handle.detect_batch_device(frames[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
+                                   marker_size=msize)
+        if world > 1:
+            return adist.gather_marker_blocks(out, cnt, dst=0)
+        return None
+
+    for i in range(args.warmup):
+        step(i)
+    handle.batch_status()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    handle.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    handle.batch_status()                       # raises on any device-side list overflow
+    elapsed = adist.max_over_ranks(elapsed, dev)
+    ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch stream over the timed steps
+    handle.enable_timing(False)
+
+    # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
+    n_host = cnt.cpu().numpy()
+    arr = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAP)
+    off = ((args.steps - 1) % nwin) * B
+    found = 0
+    for f in range(B):
+        ids = set(int(x) for x in arr[f, :min(n_host[f], CAP)]["id"])
+        tids = set(t["id"] for t in truth[off + f])
+        if not ids <= tids:
+            raise SystemExit("frame %d: detected ids %s not a subset of rendered ids" % (f, sorted(ids - tids)))
+        found += len(ids)
+    rendered = sum(len(truth[off + f]) for f in range(B))
+    if found < 0.9 * rendered:
+        raise SystemExit("only %d of %d rendered markers detected" % (found, rendered))
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        fps = total_frames / elapsed
+        dom = max(ktimes, key=lambda k: ktimes[k])
+        dom_ms = ktimes[dom]
+        achieved = ALG_BYTES_PER_FRAME * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if dom in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * B
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "frames/sec at 1920x1080", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1920x1080 synthetic stream, ~20 markers/frame, threshold+contour+decode+LINES"
+                                   + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"),
+                       "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 20,
+                       "markers_detected_per_frame": round(found / B, 2), "parallelism": "frames sharded 1 stream/GPU"
+                       + (", RCCL gather of marker blocks per step" if world > 1 else "")},
+            "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
+            "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * B, "avg_launch_ms": round(dom_ms, 4)},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in ktimes.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nsample = min(32, args.frames)
+            res["cpu_baseline"] = cpu_baseline(frames[:nsample].cpu().numpy())
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

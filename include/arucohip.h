@@ -154,6 +154,10 @@ int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hol
 /* Candidates after detectRectangles in reference order: integer quad, decoded id (-1 none), nRotations. */
 int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int32_t* ids, int32_t* nrot, int cap, int* n);
 
+/* Device list fill levels of the last batch: [0] border-start candidates, [1] borders kept, [2] contour points,
+ * [3] overflow bits. For sizing arucohip_limits_t. */
+int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8);
+
 /* BoardDetector::detect (boarddetector.h:103-108). markers: output of arucohip_detect; ids/obj: BoardConfiguration
  * (board.h:56-69) as nboard ids and nboard*4*3 floats; returns likelihood in *prob (found / total).
  * out_markers (cap n) receives the board's member markers (Board : vector<Marker>). */
@@ -166,11 +170,15 @@ int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, 
 int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers, int n, const float* K, const float* dist,
                                   int ndist, float marker_size, int y_perpendicular);
 
-/* Per-stage device time of the last batch in milliseconds (hipEvent pairs on the handle's stream), the reference's
+/* Per-stage device time per batch in milliseconds (hipEvent pairs on the handle's stream), the reference's
  * ARUCO_MARKER_BENCHMARK stages (markerdetector.cpp:472-476): names via arucohip_stage_name. Returns count. */
 int arucohip_stage_times(arucohip_handle* h, float* ms, int cap);
 const char* arucohip_stage_name(int i);
+/* on != 0 starts recording (and resets the average); up to 32 batches are averaged. */
 int arucohip_enable_timing(arucohip_handle* h, int on);
+/* Per-kernel average device time (ms per batch) since arucohip_enable_timing; names via arucohip_kernel_name. */
+int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap);
+const char* arucohip_kernel_name(int i);
 
 #ifdef __cplusplus
 }
