@@ -1,0 +1,498 @@
+// Header-only C++ shim: the reference's classes for the detection path, implemented on the arucohip C ABI.
+//
+//   aruco::MarkerDetector   /root/reference/src/markerdetector.h:42-310
+//   aruco::Marker           /root/reference/src/marker.h:43-140
+//   aruco::CameraParameters /root/reference/src/cameraparameters.h:36-127 (data + resize only)
+//   aruco::BoardConfiguration, aruco::Board  /root/reference/src/board.h:54-137 (data only)
+//   aruco::BoardDetector    /root/reference/src/boarddetector.h:40-148
+//
+// Same member names, argument meaning and failure behaviour (CV_Assert -> cv::Exception) as the reference, so a caller
+// of the reference compiles against this header and links libarucohip.so instead of libaruco + OpenCV imgproc/calib3d.
+// When <opencv2/core.hpp> is on the include path the real cv:: types are used; otherwise a minimal stand-in with the
+// same spelling (cv::Mat view, Point2f, Point3f, Size, Mat_<T>, Exception) keeps the header self-contained — that is
+// the configuration tested in this repository (OpenCV is not installed in the build image).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "arucohip.h"
+
+#if defined(ARUCOHIP_USE_OPENCV) || (defined(__has_include) && __has_include(<opencv2/core.hpp>) && !defined(ARUCOHIP_NO_OPENCV))
+#include <opencv2/core.hpp>
+#define ARUCOHIP_HAVE_OPENCV 1
+#else
+#define ARUCOHIP_HAVE_OPENCV 0
+namespace cv {
+enum { CV_8UC1_ = 0, CV_8UC3_ = 16, CV_32FC1_ = 5, CV_64FC1_ = 6 };
+#ifndef CV_8UC1
+#define CV_8UC1 cv::CV_8UC1_
+#define CV_8UC3 cv::CV_8UC3_
+#define CV_32FC1 cv::CV_32FC1_
+#define CV_64FC1 cv::CV_64FC1_
+#endif
+struct Point2f {
+    float x, y;
+    Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {}
+};
+struct Point3f {
+    float x, y, z;
+    Point3f(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {}
+};
+struct Size {
+    int width, height;
+    Size(int w = 0, int h = 0) : width(w), height(h) {}
+    bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+};
+inline std::ostream& operator<<(std::ostream& s, const Point2f& p) { return s << "[" << p.x << ", " << p.y << "]"; }
+class Exception : public std::runtime_error {
+public:
+    int code;
+    Exception(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+// Dense 2-D array: owns its storage or views caller memory (like a cv::Mat header over external data).
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    unsigned char* data = nullptr;
+    Mat() {}
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), data((unsigned char*)ext), type_(type) {
+        step = step_ ? step_ : (size_t)c * elemSize();
+    }
+    void create(int r, int c, int type) {
+        type_ = type, rows = r, cols = c;
+        step = (size_t)c * elemSize();
+        store_ = std::make_shared<std::vector<unsigned char> >((size_t)r * step, (unsigned char)0);
+        data = store_->data();
+    }
+    static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
+    int type() const { return type_; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    size_t total() const { return (size_t)rows * cols; }
+    size_t elemSize() const { return type_ == CV_8UC1_ ? 1 : type_ == CV_8UC3_ ? 3 : type_ == CV_32FC1_ ? 4 : 8; }
+    Size size() const { return Size(cols, rows); }
+    template <class T> T& at(int r, int c) { return *(T*)(data + (size_t)r * step + (size_t)c * sizeof(T)); }
+    template <class T> const T& at(int r, int c) const { return *(const T*)(data + (size_t)r * step + (size_t)c * sizeof(T)); }
+    template <class T> T* ptr(int r = 0) { return (T*)(data + (size_t)r * step); }
+    template <class T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }
+    Mat clone() const {
+        Mat m(rows, cols, type_);
+        for (int r = 0; r < rows; r++) std::memcpy(m.data + (size_t)r * m.step, data + (size_t)r * step, (size_t)cols * elemSize());
+        return m;
+    }
+protected:
+    int type_ = CV_8UC1_;
+    std::shared_ptr<std::vector<unsigned char> > store_;
+};
+template <class T> struct MatDepth_;
+template <> struct MatDepth_<float> { enum { value = CV_32FC1_ }; };
+template <> struct MatDepth_<double> { enum { value = CV_64FC1_ }; };
+template <> struct MatDepth_<unsigned char> { enum { value = CV_8UC1_ }; };
+template <class T> class Mat_ : public Mat {
+public:
+    Mat_() { type_ = MatDepth_<T>::value; }
+    Mat_(int r, int c) : Mat(r, c, MatDepth_<T>::value) {}
+    T& operator()(int r, int c) { return at<T>(r, c); }
+    const T& operator()(int r, int c) const { return at<T>(r, c); }
+    T& operator()(int i) { return ((T*)data)[i]; }
+    const T& operator()(int i) const { return ((const T*)data)[i]; }
+};
+typedef const Mat& InputArray;
+typedef Mat& OutputArray;
+}  // namespace cv
+#endif
+
+namespace aruco {
+
+inline void arucohip_throw_(int rc, const char* what, arucohip_handle* h) {
+    if (rc == ARUCOHIP_OK) return;
+    std::string msg = std::string(what) + ": " + (h ? arucohip_last_error_string(h) : "") + " (arucohip status " + std::to_string(rc) + ")";
+    throw cv::Exception(rc == ARUCOHIP_E_INVALID ? -215 /* StsAssert */ : -2, msg
+#if ARUCOHIP_HAVE_OPENCV
+                        , "arucohip", __FILE__, __LINE__
+#endif
+    );
+}
+
+// ---- small conversions between the caller's matrices and the ABI's plain arrays
+inline bool mat_to_K_(const cv::Mat& m, float K[9]) {
+    if (m.empty()) return false;
+    if (m.rows != 3 || m.cols != 3) arucohip_throw_(ARUCOHIP_E_INVALID, "camera matrix must be 3x3", nullptr);
+    for (int i = 0; i < 9; i++)
+        K[i] = m.type() == CV_64FC1 ? (float)m.at<double>(i / 3, i % 3) : m.at<float>(i / 3, i % 3);
+    return true;
+}
+inline int mat_to_dist_(const cv::Mat& m, float d[8]) {
+    if (m.empty()) return 0;
+    int n = (int)std::min<size_t>(m.total(), 8);
+    for (int i = 0; i < n; i++) {
+        int r = m.cols == 1 ? i : 0, c = m.cols == 1 ? 0 : i;
+        d[i] = m.type() == CV_64FC1 ? (float)m.at<double>(r, c) : m.at<float>(r, c);
+    }
+    return n;
+}
+
+class CameraParameters {
+public:
+    cv::Mat_<float> CameraMatrix;  // 3x3 (fx 0 cx, 0 fy cy, 0 0 1)
+    cv::Mat_<float> Distorsion;    // k1,k2,p1,p2[,k3]
+    cv::Size CamSize;
+    CameraParameters() : CamSize(-1, -1) {}
+    CameraParameters(const float K[9], const float* dist, int ndist, cv::Size size) { setParams(K, dist, ndist, size); }
+    void setParams(const float K[9], const float* dist, int ndist, cv::Size size) {
+        CameraMatrix = cv::Mat_<float>(3, 3);
+        for (int i = 0; i < 9; i++) CameraMatrix(i / 3, i % 3) = K[i];
+        Distorsion = cv::Mat_<float>(1, ndist);
+        for (int i = 0; i < ndist; i++) Distorsion(0, i) = dist[i];
+        CamSize = size;
+    }
+    bool isValid() const { return !CameraMatrix.empty() && !Distorsion.empty() && CamSize.width != -1 && CamSize.height != -1; }
+    // cameraparameters.cpp:166-179
+    void resize(cv::Size size) {
+        if (!isValid()) arucohip_throw_(ARUCOHIP_E_INVALID, "invalid camera parameters", nullptr);
+        if (size == CamSize) return;
+        float AxFactor = float(size.width) / float(CamSize.width);
+        float AyFactor = float(size.height) / float(CamSize.height);
+        CameraMatrix(0, 0) *= AxFactor;
+        CameraMatrix(0, 2) *= AxFactor;
+        CameraMatrix(1, 1) *= AyFactor;
+        CameraMatrix(1, 2) *= AyFactor;
+    }
+};
+
+class Marker : public std::vector<cv::Point2f> {
+public:
+    int id;
+    float ssize;
+    cv::Mat_<double> Rvec, Tvec;
+    Marker() : id(-1), ssize(-1) {}
+    explicit Marker(const std::vector<cv::Point2f>& corners, int _id = -1) : std::vector<cv::Point2f>(corners), id(_id), ssize(-1) {}
+    bool isValid() const { return id != -1 && size() == 4; }
+    cv::Point2f getCenter() const {
+        cv::Point2f cent(0, 0);
+        for (size_t i = 0; i < size(); i++) cent.x += (*this)[i].x, cent.y += (*this)[i].y;
+        cent.x /= float(size());
+        cent.y /= float(size());
+        return cent;
+    }
+    float getPerimeter() const {  // utils.h:39-46
+        float sum = 0;
+        for (size_t i = 0; i < size(); i++) {
+            size_t j = (i + 1) % size();
+            float dx = (*this)[i].x - (*this)[j].x, dy = (*this)[i].y - (*this)[j].y;
+            sum += std::sqrt((double)dx * dx + (double)dy * dy);
+        }
+        return sum;
+    }
+    float getArea() const {  // marker.cpp:141-151
+        assert(size() == 4);
+        const Marker& m = *this;
+        float a1 = std::fabs((m[1].x - m[0].x) * (m[3].y - m[0].y) - (m[1].y - m[0].y) * (m[3].x - m[0].x));
+        float a2 = std::fabs((m[1].x - m[2].x) * (m[3].y - m[2].y) - (m[1].y - m[2].y) * (m[3].x - m[2].x));
+        return (a2 + a1) / 2.f;
+    }
+    // marker.cpp:112-124 — needs a detector handle for the device solvePnP; see MarkerDetector::calculateExtrinsics
+    friend bool operator<(const Marker& a, const Marker& b) { return a.id < b.id; }
+    friend std::ostream& operator<<(std::ostream& str, const Marker& M) {  // marker.h:128-139
+        str << M.id << "=";
+        for (int i = 0; i < 4 && i < (int)M.size(); i++) str << "(" << M[i].x << "," << M[i].y << ") ";
+        if (!M.Tvec.empty() && !M.Rvec.empty()) {
+            str << "Txyz=" << M.Tvec(0) << " " << M.Tvec(1) << " " << M.Tvec(2) << " ";
+            str << "Rxyz=" << M.Rvec(0) << " " << M.Rvec(1) << " " << M.Rvec(2) << " ";
+        }
+        return str;
+    }
+    void to_abi(arucohip_marker_t* o) const {
+        std::memset(o, 0, sizeof(*o));
+        o->id = id, o->ssize = ssize;
+        for (int k = 0; k < 4 && k < (int)size(); k++) o->corners[2 * k] = (*this)[k].x, o->corners[2 * k + 1] = (*this)[k].y;
+        if (!Rvec.empty() && !Tvec.empty()) {
+            o->has_pose = 1;
+            for (int k = 0; k < 3; k++) o->rvec[k] = Rvec(k), o->tvec[k] = Tvec(k);
+        }
+    }
+    static Marker from_abi(const arucohip_marker_t& m) {
+        Marker r;
+        r.id = m.id, r.ssize = m.ssize;
+        for (int k = 0; k < 4; k++) r.push_back(cv::Point2f(m.corners[2 * k], m.corners[2 * k + 1]));
+        if (m.has_pose) {
+            r.Rvec = cv::Mat_<double>(3, 1), r.Tvec = cv::Mat_<double>(3, 1);
+            for (int k = 0; k < 3; k++) r.Rvec(k) = m.rvec[k], r.Tvec(k) = m.tvec[k];
+        }
+        return r;
+    }
+};
+
+class BoardConfiguration {
+public:
+    std::vector<int> ids;
+    std::vector<std::vector<cv::Point3f> > objPoints;
+    enum MarkerInfoType { NONE = -1, PIX = 0, METERS = 1 };
+    int mInfoType;
+    BoardConfiguration() : mInfoType(NONE) {}
+    bool isExpressedInMeters() const { return mInfoType == METERS; }
+    bool isExpressedInPixels() const { return mInfoType == PIX; }
+    const std::vector<cv::Point3f>& getMarkerInfo(int id) const {  // board.cpp:60-66
+        for (size_t i = 0; i < ids.size(); i++)
+            if (ids[i] == id) return objPoints[i];
+        arucohip_throw_(ARUCOHIP_E_INVALID, "BoardConfiguration::getMarkerInfo: marker with the id given is not found", nullptr);
+        return objPoints[0];
+    }
+};
+
+class Board : public std::vector<Marker> {
+public:
+    BoardConfiguration conf;
+    cv::Mat_<double> Rvec, Tvec;
+};
+
+class MarkerDetector {
+public:
+    enum ThresholdMethods { FIXED_THRES, ADPT_THRES, CANNY };
+    enum CornerRefinementMethod { NONE, HARRIS, SUBPIX, LINES };
+
+    explicit MarkerDetector(int device = 0) : h_(nullptr), device_(device), cap_w_(0), cap_h_(0) { arucohip_default_params(&p_); }
+    ~MarkerDetector() { arucohip_destroy(h_); }
+    MarkerDetector(const MarkerDetector&) = delete;
+    MarkerDetector& operator=(const MarkerDetector&) = delete;
+
+    // markerdetector.h:102-103
+    void detect(const cv::Mat& input, std::vector<Marker>& detectedMarkers, cv::Mat camMatrix = cv::Mat(), cv::Mat distCoeff = cv::Mat(),
+                float markerSizeMeters = -1, bool setYPerpendicular = false) {
+        if (input.type() != CV_8UC1)
+            arucohip_throw_(ARUCOHIP_E_INVALID, "detect: the accelerated path takes 8-bit gray frames (convert BGR with the caller's cvtColor)", nullptr);
+        ensure_(input.cols, input.rows);
+        float K[9], d[8];
+        bool hasK = mat_to_K_(camMatrix, K);
+        int nd = mat_to_dist_(distCoeff, d);
+        std::vector<arucohip_marker_t> out(256);
+        int n = 0;
+        int rc = arucohip_detect(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
+                                 setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n);
+        arucohip_throw_(rc, "MarkerDetector::detect", h_);
+        detectedMarkers.clear();
+        for (int i = 0; i < n; i++) detectedMarkers.push_back(Marker::from_abi(out[i]));
+        frame_size_ = cv::Size(input.cols, input.rows);
+        thres_valid_ = false, cand_valid_ = false;
+    }
+    // markerdetector.h:116-120
+    void detect(const cv::Mat& input, std::vector<Marker>& detectedMarkers, const CameraParameters& camParams, float markerSizeMeters = -1,
+                bool setYPerpendicular = false) {
+        detect(input, detectedMarkers, camParams.CameraMatrix, camParams.Distorsion, markerSizeMeters, setYPerpendicular);
+    }
+
+    void setThresholdMethod(ThresholdMethods m) { p_.thres_method = (int)m, push_(); }
+    ThresholdMethods getThresholdMethod() const { return (ThresholdMethods)p_.thres_method; }
+    void setThresholdParams(double param1, double param2) { p_.thres_param1 = param1, p_.thres_param2 = param2, push_(); }
+    void setThresholdParamRange(size_t r1 = 0, size_t = 0) { p_.thres_param1_range = (int)r1, recreate_(); }
+    void getThresholdParams(double& param1, double& param2) const { param1 = p_.thres_param1, param2 = p_.thres_param2; }
+    void enableLockedCornersMethod(bool enable) {  // markerdetector.cpp:291-295
+        p_.use_locked_corners = enable;
+        if (enable) p_.corner_method = SUBPIX;
+        push_();
+    }
+    const cv::Mat& getThresholdedImage() {  // markerdetector.h:183
+        if (!thres_valid_ && h_ && frame_size_.width > 0) {
+            thres_ = cv::Mat(frame_size_.height, frame_size_.width, CV_8UC1);
+            arucohip_throw_(arucohip_get_thresholded(h_, 0, thres_.data), "getThresholdedImage", h_);
+            thres_valid_ = true;
+        }
+        return thres_;
+    }
+    void setCornerRefinementMethod(CornerRefinementMethod m) { p_.corner_method = (int)m, push_(); }
+    CornerRefinementMethod getCornerRefinementMethod() const { return (CornerRefinementMethod)p_.corner_method; }
+    void setMinMaxSize(float min = 0.03f, float max = 0.5f) {  // CV_Assert ranges: markerdetector.cpp:1031-1038
+        arucohip_params_t q = p_;
+        q.min_size = min, q.max_size = max;
+        check_(q);
+        p_ = q, push_();
+    }
+    void getMinMaxSize(float& min, float& max) { min = p_.min_size, max = p_.max_size; }
+    void setDesiredSpeed(int val) {  // markerdetector.cpp:265-285
+        if (val < 0) val = 0;
+        else if (val > 3) val = 2;
+        speed_ = val;
+        if (val == 0) p_.warp_size = 56, p_.corner_method = SUBPIX;
+        else if (val == 1 || val == 2) p_.warp_size = 28, p_.corner_method = NONE;
+        push_();
+    }
+    int getDesiredSpeed() const { return speed_; }
+    void setWarpSize(int val) {  // CV_Assert(val >= 10): markerdetector.cpp:1047-1051
+        arucohip_params_t q = p_;
+        q.warp_size = val;
+        check_(q);
+        p_ = q, push_();
+    }
+    int getWarpSize() const { return p_.warp_size; }
+    const std::vector<std::vector<cv::Point2f> >& getCandidates() {  // markerdetector.h:266
+        if (!cand_valid_ && h_) {
+            std::vector<float> q(512 * 8);
+            int n = 0;
+            arucohip_throw_(arucohip_get_candidates(h_, 0, q.data(), 512, &n), "getCandidates", h_);
+            candidates_.assign(n, std::vector<cv::Point2f>(4));
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < 4; k++) candidates_[i][k] = cv::Point2f(q[i * 8 + 2 * k], q[i * 8 + 2 * k + 1]);
+            cand_valid_ = true;
+        }
+        return candidates_;
+    }
+    // stage entry points (markerdetector.h:255-280)
+    void thresHold(int method, const cv::Mat& grey, cv::Mat& thresImg, double param1 = -1, double param2 = -1) {
+        if (grey.type() != CV_8UC1) arucohip_throw_(ARUCOHIP_E_INVALID, "thresHold: grey.type() == CV_8UC1", nullptr);  // :644
+        ensure_(grey.cols, grey.rows);
+        thresImg = cv::Mat(grey.rows, grey.cols, CV_8UC1);
+        arucohip_throw_(arucohip_threshold(h_, method, grey.data, grey.cols, grey.rows, grey.step, param1, param2, thresImg.data), "thresHold", h_);
+    }
+    void detectRectangles(const cv::Mat& thresImg, std::vector<std::vector<cv::Point2f> >& candidates) {
+        ensure_(thresImg.cols, thresImg.rows);
+        std::vector<float> q(512 * 8);
+        int n = 0;
+        arucohip_throw_(arucohip_detect_rectangles(h_, thresImg.data, thresImg.cols, thresImg.rows, thresImg.step, q.data(), 512, &n), "detectRectangles", h_);
+        candidates.assign(n, std::vector<cv::Point2f>(4));
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++) candidates[i][k] = cv::Point2f(q[i * 8 + 2 * k], q[i * 8 + 2 * k + 1]);
+    }
+    void warp(const cv::Mat& in, cv::Mat& out, cv::Size size, std::vector<cv::Point2f> points) {
+        if (points.size() != 4) arucohip_throw_(ARUCOHIP_E_INVALID, "warp: points.size() == 4", nullptr);  // :685
+        ensure_(in.cols, in.rows);
+        float q[8];
+        for (int k = 0; k < 4; k++) q[2 * k] = points[k].x, q[2 * k + 1] = points[k].y;
+        out = cv::Mat(size.height, size.width, CV_8UC1);
+        arucohip_throw_(arucohip_warp(h_, in.data, in.cols, in.rows, in.step, q, size.width, out.data), "warp", h_);
+    }
+    // Marker::calculateExtrinsics for a whole vector at once (batched device solvePnP)
+    void calculateExtrinsics(std::vector<Marker>& markers, float markerSize, cv::Mat camMatrix, cv::Mat distCoeff = cv::Mat(), bool setYPerpendicular = true) {
+        if (markers.empty()) return;
+        ensure_(std::max(cap_w_, 64), std::max(cap_h_, 64));
+        float K[9], d[8];
+        if (!mat_to_K_(camMatrix, K)) arucohip_throw_(ARUCOHIP_E_INVALID, "CameraMatrix is empty", nullptr);
+        int nd = mat_to_dist_(distCoeff, d);
+        std::vector<arucohip_marker_t> m(markers.size());
+        for (size_t i = 0; i < markers.size(); i++) markers[i].to_abi(&m[i]);
+        arucohip_throw_(arucohip_calculate_extrinsics(h_, m.data(), (int)m.size(), K, nd ? d : nullptr, nd, markerSize, setYPerpendicular), "calculateExtrinsics", h_);
+        for (size_t i = 0; i < markers.size(); i++) markers[i] = Marker::from_abi(m[i]);
+    }
+    arucohip_handle* handle(int w = 640, int h = 480) {
+        ensure_(std::max(w, cap_w_), std::max(h, cap_h_));
+        return h_;
+    }
+
+private:
+    void check_(const arucohip_params_t& q) {
+        arucohip_handle* tmp = h_;
+        if (!tmp) ensure_(640, 480), tmp = h_;
+        arucohip_params_t saved;
+        arucohip_get_params(tmp, &saved);
+        int rc = arucohip_set_params(tmp, &q);
+        if (rc != ARUCOHIP_OK) {
+            arucohip_set_params(tmp, &saved);
+            arucohip_throw_(rc, "MarkerDetector parameter", tmp);
+        }
+    }
+    void push_() {
+        if (h_) arucohip_throw_(arucohip_set_params(h_, &p_), "MarkerDetector parameter", h_);
+    }
+    void recreate_() {
+        if (!h_) return;
+        int w = cap_w_, hh = cap_h_;
+        arucohip_destroy(h_);
+        h_ = nullptr, cap_w_ = cap_h_ = 0;
+        ensure_(w, hh);
+    }
+    void ensure_(int w, int hh) {
+        if (h_ && (size_t)w * hh <= (size_t)cap_w_ * cap_h_) return;
+        arucohip_destroy(h_);
+        h_ = nullptr;
+        arucohip_throw_(arucohip_create(&p_, device_, w, hh, 1, &h_), "arucohip_create", nullptr);
+        cap_w_ = w, cap_h_ = hh;
+    }
+    arucohip_handle* h_;
+    int device_, cap_w_, cap_h_;
+    arucohip_params_t p_;
+    int speed_ = 0;
+    cv::Size frame_size_;
+    cv::Mat thres_;
+    bool thres_valid_ = false, cand_valid_ = false;
+    std::vector<std::vector<cv::Point2f> > candidates_;
+};
+
+class BoardDetector {
+public:
+    explicit BoardDetector(bool setYPerpendicular = false) : _setYPerpendicular(setYPerpendicular), _areParamsSet(false), _markerSize(-1), repj_err_thres(-1) {}
+    void setParams(const BoardConfiguration& bc, const CameraParameters& cp, float markerSizeMeters = -1) {
+        _camParams = cp, _markerSize = markerSizeMeters, _bconf = bc, _areParamsSet = true;
+    }
+    void setParams(const BoardConfiguration& bc) { _bconf = bc, _areParamsSet = true; }
+    // boarddetector.cpp:66-77
+    float detect(const cv::Mat& im) {
+        _mdetector.detect(im, _vmarkers);
+        if (_camParams.isValid())
+            return detect(_vmarkers, _bconf, _boardDetected, _camParams.CameraMatrix, _camParams.Distorsion, _markerSize);
+        return detect(_vmarkers, _bconf, _boardDetected);
+    }
+    float detect(const std::vector<Marker>& detectedMarkers, const BoardConfiguration& BConf, Board& Bdetected, const CameraParameters& cp,
+                 float markerSizeMeters = -1) {
+        return detect(detectedMarkers, BConf, Bdetected, cp.CameraMatrix, cp.Distorsion, markerSizeMeters);
+    }
+    // boarddetector.cpp:90-205
+    float detect(const std::vector<Marker>& detectedMarkers, const BoardConfiguration& BConf, Board& Bdetected, cv::Mat camMatrix = cv::Mat(),
+                 cv::Mat distCoeff = cv::Mat(), float markerSizeMeters = -1) {
+        float K[9], d[8];
+        bool hasK = mat_to_K_(camMatrix, K);
+        int nd = mat_to_dist_(distCoeff, d);
+        std::vector<arucohip_marker_t> in(std::max<size_t>(detectedMarkers.size(), 1)), out(std::max<size_t>(detectedMarkers.size(), 1));
+        for (size_t i = 0; i < detectedMarkers.size(); i++) detectedMarkers[i].to_abi(&in[i]);
+        std::vector<int32_t> ids(BConf.ids.begin(), BConf.ids.end());
+        std::vector<float> obj;
+        for (size_t i = 0; i < BConf.objPoints.size(); i++)
+            for (int p = 0; p < 4 && p < (int)BConf.objPoints[i].size(); p++)
+                obj.push_back(BConf.objPoints[i][p].x), obj.push_back(BConf.objPoints[i][p].y), obj.push_back(BConf.objPoints[i][p].z);
+        arucohip_board_t b;
+        float prob = 0;
+        arucohip_handle* h = _mdetector.handle();
+        int rc = arucohip_board_detect(h, in.data(), (int)detectedMarkers.size(), ids.data(), obj.data(), (int)ids.size(), BConf.mInfoType,
+                                       hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters, repj_err_thres, _setYPerpendicular ? 1 : 0,
+                                       out.data(), &b, &prob);
+        arucohip_throw_(rc, "BoardDetector::detect", h);
+        Bdetected.clear();
+        for (int i = 0; i < b.n_markers; i++) Bdetected.push_back(Marker::from_abi(out[i]));
+        Bdetected.conf = BConf;
+        if (b.has_pose) {
+            Bdetected.Rvec = cv::Mat_<double>(3, 1), Bdetected.Tvec = cv::Mat_<double>(3, 1);
+            for (int k = 0; k < 3; k++) Bdetected.Rvec(k) = b.rvec[k], Bdetected.Tvec(k) = b.tvec[k];
+        }
+        return prob;
+    }
+    static Board detect(const cv::Mat& Image, const BoardConfiguration& bc, const CameraParameters& cp, float markerSizeMeters = -1) {
+        BoardDetector BD;
+        BD.setParams(bc, cp, markerSizeMeters);
+        BD.detect(Image);
+        return BD.getDetectedBoard();
+    }
+    Board& getDetectedBoard() { return _boardDetected; }
+    MarkerDetector& getMarkerDetector() { return _mdetector; }
+    std::vector<Marker>& getDetectedMarkers() { return _vmarkers; }
+    void setYPerpendicular(bool enable) { _setYPerpendicular = enable; }
+    void set_repj_err_thres(float Repj_err_thres) { repj_err_thres = Repj_err_thres; }
+    float get_repj_err_thres() const { return repj_err_thres; }
+
+private:
+    bool _setYPerpendicular, _areParamsSet;
+    BoardConfiguration _bconf;
+    Board _boardDetected;
+    float _markerSize;
+    CameraParameters _camParams;
+    MarkerDetector _mdetector;
+    std::vector<Marker> _vmarkers;
+    float repj_err_thres;
+};
+
+}  // namespace aruco
