@@ -39,6 +39,7 @@ struct arucohip_handle {
     Buffers buf{};
     uint8_t* d_gray = nullptr;        // staging for host frames
     size_t gray_bytes = 0;
+    size_t scratch_words = 0;         // capacity of buf.walk_scratch
     // pinned host staging
     arucohip_marker_t* h_markers = nullptr;
     int32_t* h_n = nullptr;
@@ -123,7 +124,7 @@ static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
     hipFree(h->buf.thres), hipFree(h->buf.nbr), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -136,7 +137,7 @@ static void free_all(arucohip_handle* h) {
 int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* lim, arucohip_handle** out) {
     if (!out || !lim) return ARUCOHIP_E_INVALID;
     *out = nullptr;
-    if (lim->max_width < 8 || lim->max_height < 8 || lim->max_width > 32767 || lim->max_height > 32767 || lim->max_batch < 1 ||
+    if (lim->max_width < 8 || lim->max_height < 8 || lim->max_width > 16383 || lim->max_height > 16383 || lim->max_batch < 1 ||
         lim->max_thres_planes < 1 || lim->max_thres_planes > 16 || lim->candidates_per_frame > 512 || lim->markers_per_frame > 256)
         return ARUCOHIP_E_INVALID;
     arucohip_handle* h = new arucohip_handle();
@@ -341,6 +342,17 @@ static int check_status(arucohip_handle* h, uint32_t st) {
     return ARUCOHIP_E_OVERFLOW;
 }
 
+// the walkers keep one checkpoint ring per lane in HBM; (re)size it for this batch
+static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
+    size_t need = (size_t)nplanes * WALK_BLOCKS * 64 * ((dp.max_contour + 31) / 32);
+    if (need <= h->scratch_words) return ARUCOHIP_OK;
+    if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
+    h->buf.walk_scratch = nullptr, h->scratch_words = 0;
+    HIPCHK(h, hipMalloc((void**)&h->buf.walk_scratch, need * sizeof(uint32_t)));
+    h->scratch_words = need;
+    return ARUCOHIP_OK;
+}
+
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
     launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
@@ -351,6 +363,10 @@ static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, 
 static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp, const CamModel& cam) {
     hipStream_t s = h->stream;
     Buffers& b = h->buf;
+    {
+        int rc_ = ensure_walk_scratch(h, nframes * dp.nthr, dp);
+        if (rc_) return rc_;
+    }
     HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
@@ -641,6 +657,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    if ((rc = ensure_walk_scratch(h, 1, dp))) return rc;
     launch_binary_planes(h->stream, dev, g, 1, h->buf);
     run_rectangles(h, g, 1, dp);
     HIPCHK(h, hipGetLastError());

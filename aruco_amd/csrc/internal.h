@@ -20,6 +20,7 @@ namespace ah {
 
 constexpr int WAVE = 64;
 constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters
+constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
 enum Counter {
     CNT_UNUSED0 = 0,
@@ -97,6 +98,7 @@ struct Buffers {
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE] fill level of each plane's list (one counter per 128-byte line)
     ContourDesc* cdesc;
     short2* pool;
+    uint32_t* walk_scratch; // checkpoint rings of the walker lanes
     Quad* quads;
     Cand* cands;
     int32_t* ncands;       // [F]

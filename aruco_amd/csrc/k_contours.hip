@@ -45,6 +45,11 @@ __device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
     return (sh + k) & 7;
 }
 
+constexpr int CK = 32;   // border steps between two checkpoints
+
+// A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
+__device__ __forceinline__ uint32_t pack_ck(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)s << 28); }
+
 struct WalkArgs {
     const uint8_t* nbr;
     const uint2* trig;
@@ -54,6 +59,9 @@ struct WalkArgs {
     uint32_t cap_trig, cap_cdesc, cap_pool;
     int width, height;
     int min_contour, max_contour;
+    uint32_t* scratch;     // [lanes in the grid][maxck] private checkpoint ring of every walker lane
+    short2* pool;          // checkpoints of a kept border are copied in front of its point range
+    int maxck;
 };
 
 // Kernel 2: one lane per start candidate; blockIdx.y = plane.
@@ -73,7 +81,9 @@ __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
         const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
         int x = x0, y = y0, n = 0;
         bool ok = true;
+        uint32_t* ck = a.scratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) * a.maxck;
         for (;;) {
+            if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(x, y, s);
             uint32_t ex;
             int d = next_dir(m, s, &ex);
             if (hole) {
@@ -98,15 +108,20 @@ __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
             m = nb[(size_t)y * W + x];
         }
         if (!ok || n <= a.min_contour) continue;
+        const int ncp = (n + CK - 1) / CK;
         uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
-        uint32_t off = atomicAdd(&a.counters[CNT_POOL], (uint32_t)n);
+        uint32_t off = atomicAdd(&a.counters[CNT_POOL], (uint32_t)(n + ncp));
         if (slot >= a.cap_cdesc) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
             continue;
         }
-        if (off + (uint32_t)n > a.cap_pool) {
+        if (off + (uint32_t)(n + ncp) > a.cap_pool) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
             n = 0;  // keeps list consistent; a zero-length contour is ignored downstream
+        } else {
+            uint32_t* dst = (uint32_t*)(a.pool + off);
+            for (int k = 0; k < ncp; k++) dst[k] = ck[k];
+            off += (uint32_t)ncp;   // points follow the checkpoints
         }
         ContourDesc cd;
         cd.plane = plane, cd.x0 = (int16_t)x0, cd.y0 = (int16_t)y0, cd.hole = hole, cd.n = n;
@@ -121,8 +136,9 @@ void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const Detect
     a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
+    a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
-    hipLaunchKernelGGL(walker_kernel, dim3(16, nplanes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(walker_kernel, dim3(WALK_BLOCKS, nplanes), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -161,19 +177,24 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
         const int count = cd.n;
         __syncthreads();
         if (count <= 0) continue;
-        // ---- emit the border (same walk as kernel 2, now recording points)
-        if (lane == 0) {
+        // ---- emit the border: every lane resumes the walk at one checkpoint and records CK points
+        {
             const uint8_t* nb = a.nbr + (size_t)cd.plane * W * a.height;
-            int x = cd.x0, y = cd.y0;
-            uint32_t m = nb[(size_t)y * W + x];
-            int s = first_dir(m, cd.hole ? 0 : 4);
-            for (int n = 0; n < count; n++) {
-                uint32_t ex;
-                int d = next_dir(m, s, &ex);
-                P[n] = make_short2((short)x, (short)y);
-                x += dir_dx(d), y += dir_dy(d);
-                s = (d + 4) & 7;
-                m = nb[(size_t)y * W + x];
+            const int ncp = (count + CK - 1) / CK;
+            const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
+            for (int k = lane; k < ncp; k += WAVE) {
+                const uint32_t c = ckp[k];
+                int x = (int)(c & 0x3FFFu), y = (int)((c >> 14) & 0x3FFFu), s = (int)(c >> 28);
+                uint32_t m = nb[(size_t)y * W + x];
+                const int n0 = k * CK, n1 = min(n0 + CK, count);
+                for (int n = n0; n < n1; n++) {
+                    uint32_t ex;
+                    int d = next_dir(m, s, &ex);
+                    P[n] = make_short2((short)x, (short)y);
+                    x += dir_dx(d), y += dir_dy(d);
+                    s = (d + 4) & 7;
+                    m = nb[(size_t)y * W + x];
+                }
             }
         }
         __syncthreads();

@@ -126,7 +126,7 @@ struct DecodeArgs {
 };
 
 __global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
-    __shared__ uint8_t patch[MAX_WARP * MAX_WARP];
+    extern __shared__ __align__(16) uint8_t patch[];   // ws*ws bytes
     __shared__ int hist[256];
     __shared__ double sA[64], sb[8], siM[9];
     __shared__ int s_thr;
@@ -226,7 +226,7 @@ void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int n
     DecodeArgs a;
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride, a.width = g.width, a.height = g.height;
     a.ws = p.warp_size, a.cands = b.cands, a.ncands = b.ncands, a.cap_cands = b.cap_cands;
-    hipLaunchKernelGGL(decode_kernel, dim3(b.cap_cands, nframes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(decode_kernel, dim3(b.cap_cands, nframes), dim3(64), (size_t)((p.warp_size * p.warp_size + 15) & ~15), s, a);
 }
 
 // MarkerDetector::warp as a stage entry point: one patch from one quad
