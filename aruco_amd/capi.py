@@ -315,4 +315,4 @@ class Handle:
     def debug_counters(self):
         c = np.zeros(8, np.uint32)
         self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
-        return {"triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}
+        return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}

@@ -40,6 +40,8 @@ struct arucohip_handle {
     uint8_t* d_gray = nullptr;        // staging for host frames
     size_t gray_bytes = 0;
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
+    size_t bits_bytes = 0;
+    int bits_w = 0, bits_h = 0;       // geometry the bit image was last written with (pad words depend on it)
     // pinned host staging
     arucohip_marker_t* h_markers = nullptr;
     int32_t* h_n = nullptr;
@@ -122,7 +124,7 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
 
 static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
-    hipFree(h->buf.thres), hipFree(h->buf.nbr), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -164,7 +166,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     h->stream = h->own_stream;
     const size_t F = lim->max_batch, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
-    b.cap_trig = (uint32_t)lim->triggers_per_frame;
+    b.cap_raw = (uint32_t)lim->triggers_per_frame;
+    b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame / 4, 4096);
     b.cap_cdesc = (uint32_t)std::min<size_t>(P * lim->contours_per_frame, 0xFFFFFFF0u);
     b.cap_pool = (uint32_t)std::min<size_t>(P * lim->points_per_frame, 0xFFFFFFF0u);
     b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);
@@ -172,7 +175,12 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_markers = lim->markers_per_frame;
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
-    ALLOC(b.nbr, P * px);
+    const size_t bits_bytes = P * (size_t)lim->max_height * ((size_t)lim->max_width / 32 + 2) * sizeof(uint32_t) + 64;
+    ALLOC(b.bits, bits_bytes);
+    if ((e = hipMemset(b.bits, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad words must read as zero
+    h->bits_bytes = bits_bytes;
+    ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
+    ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.cdesc, (size_t)b.cap_cdesc * sizeof(ContourDesc));
@@ -342,9 +350,17 @@ static int check_status(arucohip_handle* h, uint32_t st) {
     return ARUCOHIP_E_OVERFLOW;
 }
 
+// the pad word of every bit-image row must be zero; its position depends on the frame width
+static int ensure_bits_geometry(arucohip_handle* h, int W, int H) {
+    if (h->bits_w == W && h->bits_h == H) return ARUCOHIP_OK;
+    HIPCHK(h, hipMemsetAsync(h->buf.bits, 0, h->bits_bytes, h->stream));
+    h->bits_w = W, h->bits_h = H;
+    return ARUCOHIP_OK;
+}
+
 // the walkers keep one checkpoint ring per lane in HBM; (re)size it for this batch
 static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
-    size_t need = (size_t)nplanes * WALK_BLOCKS * 64 * ((dp.max_contour + 31) / 32);
+    size_t need = (size_t)((nplanes + 7) / 8) * 8 * WALK_BLOCKS * 64 * ((dp.max_contour + 31) / 32);
     if (need <= h->scratch_words) return ARUCOHIP_OK;
     if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
     h->buf.walk_scratch = nullptr, h->scratch_words = 0;
@@ -355,6 +371,7 @@ static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectPara
 
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
+    launch_filter(h->stream, g, nframes * dp.nthr, h->buf);
     launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
     launch_contour_quads(h->stream, g, nframes, dp, h->buf);
     launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
@@ -366,15 +383,18 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     {
         int rc_ = ensure_walk_scratch(h, nframes * dp.nthr, dp);
         if (rc_) return rc_;
+        if ((rc_ = ensure_bits_geometry(h, g.width, g.height))) return rc_;
     }
     HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
+    HIPCHK(h, hipMemsetAsync(b.raw_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
     MARK(0);
     launch_threshold(s, gray_dev, g, nframes, dp, b);
     MARK(1);
+    launch_filter(s, g, nframes * dp.nthr, b);
     launch_walkers(s, g, nframes * dp.nthr, dp, b);
     MARK(2);
     launch_contour_quads(s, g, nframes, dp, b);
@@ -607,6 +627,11 @@ int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
     uint64_t tot = 0;
     for (int p = 0; p < planes; p++) tot += tc[(size_t)p * TRIG_CNT_STRIDE];
     out8[0] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFu);
+    HIPCHK(h, hipMemcpyAsync(tc.data(), h->buf.raw_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    tot = 0;
+    for (int p = 0; p < planes; p++) tot += tc[(size_t)p * TRIG_CNT_STRIDE];
+    out8[4] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFu);
     return ARUCOHIP_OK;
 }
 
@@ -633,6 +658,8 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &gray_dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
@@ -657,7 +684,9 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     if ((rc = ensure_walk_scratch(h, 1, dp))) return rc;
+    if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_binary_planes(h->stream, dev, g, 1, h->buf);
     run_rectangles(h, g, 1, dp);
     HIPCHK(h, hipGetLastError());

@@ -2,9 +2,9 @@
 //
 // HBM layout per handle (F = frames in the batch, T = threshold planes per frame, P = F*T planes):
 //   thres [P][H][W] u8   thresholded image (API-visible product, MarkerDetector::getThresholdedImage)
-//   nbr   [P][H][W] u8   bit d set = 8-neighbour in direction d (0=E,1=NE,..7=SE, y down) is foreground, after the
-//                        1-px frame has been zeroed the way cv::findContours does
-//   trig  u32x2 list     border-start candidates {plane<<1|hole, y<<16|x}
+//   bits  [P][H][WB] u32 binary image cv::findContours works on (bit x&31 of word x>>5; 1-px frame cleared), WB = W/32 + 1 pad
+//   raw   [P][capR] u32x2 local border-start candidates {hole, y<<16|x} from kernel 1
+//   trig  [P][capT] u32x2 candidates that pass the run rule
 //   cdesc list           borders that passed the size filter {plane, start, hole, n, key, pool offset}
 //   pool  short2 list    contour points
 //   quads [F][capQ]      4-vertex convex polygons
@@ -21,6 +21,9 @@ namespace ah {
 constexpr int WAVE = 64;
 constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters
 constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
+
+// words per row of the bit image: one zero pad word so that two-word reads never leave the row
+__host__ __device__ inline int bits_pitch(int width) { return (width + 31) / 32 + 1; }
 
 enum Counter {
     CNT_UNUSED0 = 0,
@@ -93,9 +96,11 @@ struct DetectParams {
 // device pointers + capacities handed to kernels
 struct Buffers {
     uint8_t* thres;
-    uint8_t* nbr;
-    uint2* trig;           // [P][cap_trig] border-start candidates per plane
-    uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE] fill level of each plane's list (one counter per 128-byte line)
+    uint32_t* bits;        // [P][H][bits_pitch(W)]
+    uint2* raw;            // [P][cap_raw] local border-start candidates per plane
+    uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
+    uint2* trig;           // [P][cap_trig] candidates that pass the run rule
+    uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
     ContourDesc* cdesc;
     short2* pool;
     uint32_t* walk_scratch; // checkpoint rings of the walker lanes
@@ -105,7 +110,7 @@ struct Buffers {
     arucohip_marker_t* markers;
     int32_t* nmarkers;     // [F]
     uint32_t* counters;
-    uint32_t cap_trig;     // per plane
+    uint32_t cap_raw, cap_trig;   // per plane
     uint32_t cap_cdesc, cap_pool;
     int cap_quads, cap_cands, cap_markers;   // per frame
 };
@@ -113,6 +118,7 @@ struct Buffers {
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
+void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

@@ -6,7 +6,8 @@
 //
 // cv::findContours is a sequential raster scan that relabels pixels while it follows borders. The point sequence
 // of a border depends only on the binary image, its start pixel and whether it is a hole border, so the scan is
-// replaced by (a) local start candidates from kernel 1 and (b) one walker per candidate that follows the border
+// replaced by (a) local start candidates from kernel 1, thinned by the run rule (filter_kernel: the start of a border is
+// the first pixel of a horizontal run with nothing connected in the row above) and (b) one walker per candidate that follows the border
 // with OpenCV's step rule and drops itself as soon as it proves it is not the scan's start:
 //   outer border: a visited pixel precedes the start in raster order
 //   hole border : a 4-neighbour background pixel examined during the walk precedes the trigger pixel
@@ -45,13 +46,99 @@ __device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
     return (sh + k) & 7;
 }
 
+__device__ __forceinline__ uint64_t load_bits64(const uint32_t* p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 32); }
+
+// 8-neighbour occupancy byte of pixel (x,y) from the bit image: bit d = neighbour in direction d is set.
+__device__ __forceinline__ uint32_t nbr_mask(const uint32_t* bits, int wb, int x, int y) {
+    const int w = (x - 1) >> 5, sh = (x - 1) & 31;
+    const uint32_t* r = bits + (size_t)(y - 1) * wb + w;
+    const uint32_t up = (uint32_t)(load_bits64(r) >> sh) & 7u;
+    const uint32_t mid = (uint32_t)(load_bits64(r + wb) >> sh) & 7u;
+    const uint32_t dn = (uint32_t)(load_bits64(r + 2 * wb) >> sh) & 7u;
+    // up = NW,N,NE  mid = W,self,E  dn = SW,S,SE (bit 0..2)  ->  E,NE,N,NW,W,SW,S,SE (bit 0..7)
+    return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1b: run rule. A raw candidate survives only if it can be the first pixel of its component / hole in raster
+// order: outer - no set pixel 8-adjacent to its run of set pixels in the row above; hole - no clear pixel directly above
+// its run of clear pixels. Runs are followed for at most the two loaded words; longer ones keep the candidate.
+// ---------------------------------------------------------------------------------------------
+struct FilterArgs {
+    const uint32_t* bits;
+    const uint2* raw;
+    const uint32_t* raw_cnt;
+    uint2* trig;
+    uint32_t* trig_cnt;
+    uint32_t* counters;
+    uint32_t cap_raw, cap_trig;
+    int wb, height;
+};
+
+__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
+    __shared__ uint2 s_keep[256];
+    __shared__ uint32_t s_n, s_base;
+    const int plane = blockIdx.y;
+    const uint32_t nraw = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const uint32_t* bits = a.bits + (size_t)plane * a.wb * a.height;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nraw; i0 += gridDim.x * blockDim.x) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < nraw) {
+            const uint2 t = a.raw[(size_t)plane * a.cap_raw + i];
+            const int hole = (int)(t.x & 1u), x = (int)(t.y & 0xFFFFu), y = (int)(t.y >> 16);
+            const int w = x >> 5, sh = x & 31, avail = 64 - sh;
+            const uint32_t* r = bits + (size_t)y * a.wb + w;
+            const uint64_t mid = load_bits64(r) >> sh, up = load_bits64(r - a.wb) >> sh;
+            bool keep;
+            if (!hole) {
+                int L = (~mid) ? __builtin_ctzll(~mid) : 64;      // run of set pixels starting at x
+                L = min(L, avail);
+                const int hi = min(L, avail - 1);                  // blockers: row above, columns x+2 .. x+L
+                const uint64_t m = hi >= 2 ? (((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull))) & ~3ull) : 0ull;
+                keep = (up & m) == 0;
+            } else {
+                int L = mid ? __builtin_ctzll(mid) : 64;           // run of clear pixels starting at x
+                L = min(L, avail);
+                const int hi = min(L - 1, avail - 1);              // row above, columns x+1 .. x+L-1 must all be set
+                const uint64_t m = hi >= 1 ? (((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull))) & ~1ull) : 0ull;
+                keep = (~up & m) == 0;
+            }
+            if (keep) s_keep[atomicAdd(&s_n, 1u)] = t;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], n);
+            __syncthreads();
+            if (threadIdx.x < n) {
+                const uint32_t slot = s_base + threadIdx.x;
+                if (slot < a.cap_trig)
+                    a.trig[(size_t)plane * a.cap_trig + slot] = s_keep[threadIdx.x];
+                else
+                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
+    FilterArgs a;
+    a.bits = b.bits, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters;
+    a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig, a.wb = bits_pitch(g.width), a.height = g.height;
+    hipLaunchKernelGGL(filter_kernel, dim3(8, nplanes), dim3(256), 0, s, a);
+}
+
 constexpr int CK = 32;   // border steps between two checkpoints
 
 // A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
 __device__ __forceinline__ uint32_t pack_ck(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)s << 28); }
 
 struct WalkArgs {
-    const uint8_t* nbr;
+    const uint32_t* bits;
+    int wb, nplanes;
     const uint2* trig;
     const uint32_t* trig_cnt;
     ContourDesc* cdesc;
@@ -64,24 +151,27 @@ struct WalkArgs {
     int maxck;
 };
 
-// Kernel 2: one lane per start candidate; blockIdx.y = plane.
+// Kernel 2: one lane per start candidate. Workgroups are dealt round-robin over the 8 XCDs, so the linear block id is
+// unpacked such that all workgroups of one plane share an XCD and its L2 keeps that plane's 1-bit image (W*H/8 bytes).
 __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
-    const int plane = blockIdx.y;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
+    if (plane >= a.nplanes) return;
     const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE], a.cap_trig);
     const int W = a.width;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntrig; i += gridDim.x * blockDim.x) {
+    const uint32_t* bits = a.bits + (size_t)plane * a.wb * a.height;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < ntrig; i += WALK_BLOCKS * blockDim.x) {
         uint2 t = a.trig[(size_t)plane * a.cap_trig + i];
         const int hole = (int)(t.x & 1);
         const int tx = (int)(t.y & 0xFFFF), ty = (int)(t.y >> 16);
-        const uint8_t* nb = a.nbr + (size_t)plane * W * a.height;
         const int x0 = tx - hole, y0 = ty;
-        uint32_t m = nb[(size_t)y0 * W + x0];
+        uint32_t m = nbr_mask(bits, a.wb, x0, y0);
         int s = first_dir(m, hole ? 0 : 4);
         if (s < 0) continue;  // isolated pixel: 1 point, never passes the size filter
         const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
         int x = x0, y = y0, n = 0;
         bool ok = true;
-        uint32_t* ck = a.scratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) * a.maxck;
+        uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
         for (;;) {
             if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(x, y, s);
             uint32_t ex;
@@ -105,7 +195,7 @@ __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
             if (nx == x0 && ny == y0 && x == x1 && y == y1) break;
             x = nx, y = ny;
             s = (d + 4) & 7;
-            m = nb[(size_t)y * W + x];
+            m = nbr_mask(bits, a.wb, x, y);
         }
         if (!ok || n <= a.min_contour) continue;
         const int ncp = (n + CK - 1) / CK;
@@ -133,12 +223,13 @@ __global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
 
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
     WalkArgs a;
-    a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
+    a.bits = b.bits, a.wb = bits_pitch(g.width), a.nplanes = nplanes;
+    a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
-    hipLaunchKernelGGL(walker_kernel, dim3(WALK_BLOCKS, nplanes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(walker_kernel, dim3(((nplanes + 7) / 8) * 8 * WALK_BLOCKS), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -154,7 +245,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 struct QuadArgs {
-    const uint8_t* nbr;
+    const uint32_t* bits;
+    int wb;
     const ContourDesc* cdesc;
     short2* pool;
     Quad* quads;
@@ -179,13 +271,13 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
         if (count <= 0) continue;
         // ---- emit the border: every lane resumes the walk at one checkpoint and records CK points
         {
-            const uint8_t* nb = a.nbr + (size_t)cd.plane * W * a.height;
+            const uint32_t* bits = a.bits + (size_t)cd.plane * a.wb * a.height;
             const int ncp = (count + CK - 1) / CK;
             const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
             for (int k = lane; k < ncp; k += WAVE) {
                 const uint32_t c = ckp[k];
                 int x = (int)(c & 0x3FFFu), y = (int)((c >> 14) & 0x3FFFu), s = (int)(c >> 28);
-                uint32_t m = nb[(size_t)y * W + x];
+                uint32_t m = nbr_mask(bits, a.wb, x, y);
                 const int n0 = k * CK, n1 = min(n0 + CK, count);
                 for (int n = n0; n < n1; n++) {
                     uint32_t ex;
@@ -193,7 +285,7 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
                     P[n] = make_short2((short)x, (short)y);
                     x += dir_dx(d), y += dir_dy(d);
                     s = (d + 4) & 7;
-                    m = nb[(size_t)y * W + x];
+                    if (n + 1 < n1) m = nbr_mask(bits, a.wb, x, y);
                 }
             }
         }
@@ -358,7 +450,7 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
 
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     QuadArgs a;
-    a.nbr = b.nbr, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
+    a.bits = b.bits, a.wb = bits_pitch(g.width), a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
     hipLaunchKernelGGL(contour_quad_kernel, dim3(256 * 8), dim3(64), sh, s, a);

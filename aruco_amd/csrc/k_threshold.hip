@@ -1,263 +1,254 @@
-// Kernel 1 — adaptive threshold + neighbour masks + border-start candidates, one pass over the gray frame.
+// Kernel 1 — adaptive threshold + bit-packed binary image + border-start candidates, one streaming pass per frame.
 //
 // Reference: MarkerDetector::thresHold -> cv::adaptiveThreshold(MEAN_C, BINARY_INV, b, C)
 //            (/root/reference/src/markerdetector.cpp:643-677) and the raster scan of cv::findContours (:511).
-// Per 64x32 output tile a 256-thread workgroup stages the gray tile (+halo) in LDS, forms the separable integer
-// box sum, rounds the mean exactly like the u8 box filter, thresholds, and from the binary tile (1-px frame zeroed,
-// as findContours does) derives for every pixel the 8-neighbour occupancy byte and the two local start rules:
-//   outer border start : first pixel of a horizontal run of set pixels with no set pixel 8-adjacent in the row above
-//                        (the raster-first pixel of an 8-connected component is such a pixel)
-//   hole  border start : first pixel of a horizontal run of clear pixels whose left neighbour is set and which has no
-//                        clear pixel directly above (the raster-first pixel of a 4-connected background hole is such)
-// Runs are followed inside the LDS tile only (a run leaving the tile keeps its candidate). Candidates are verified by
-// the walkers (k_contours.hip). Each workgroup collects its candidates in LDS and reserves list space with one atomic
-// on its plane's counter. HBM traffic: read W*H, write 2*W*H (+ sparse list).
+//
+// One wavefront owns a vertical strip: lane l holds 4 horizontally adjacent pixels (one dword of the gray row), the wave
+// spans 256 px of which the middle 224 (lanes 4..59 = seven 32-px words) are outputs and 16 px per side are halo.
+// The wave walks down its row segment keeping, in registers only,
+//   * a ring of the last 2R+1 gray rows and of their horizontal box sums (two u16 per dword),
+//   * the running vertical sums V (added row in, row out),
+// so every gray byte is read from HBM/L2 once (plus the halo overlap), there is no LDS tile and no re-read.
+// mean = round(S / b^2) is never formed: src - mean <= -C  <=>  (src + C) * b^2 <= S + b^2/2 (exact in integers).
+// Per output row the wave stores 224 threshold bytes (one dword per lane), seven 32-bit words of the binary image
+// (1-px frame cleared, the image cv::findContours binarises) and stages the local border-start candidates
+//   outer: pixel set,  W, NW, N, NE clear         hole: pixel clear, W and N set
+// in LDS; one atomic per flush reserves space in the plane's raw candidate list. k_contours.hip filters (run rule)
+// and verifies them. HBM traffic per frame: read W*H, write W*H + W*H/8 (+ sparse lists).
 #include "internal.h"
 
 namespace ah {
 
-constexpr int TW = 64, TH = 32, NT = 256;
-
 enum ThrMode { MODE_ADPT = 0, MODE_FIXED = 1, MODE_BINARY = 2 };
+
+constexpr int STRIP_OUT = 224;   // output pixels per strip (7 words)
+constexpr int STRIP_HALO = 16;   // halo pixels per side (4 lanes) — covers box radius <= 15 plus the 1-px neighbourhood
+constexpr int SEG = 64;          // output rows per wave
+constexpr int LOCAL_TRIG = 256;
 
 struct ThrArgs {
     const uint8_t* gray;
     size_t row_stride, frame_stride;
     int width, height;
     int nthr, t;          // planes per frame, plane handled by this launch
-    int R;                // box radius
     int idelta;           // ADPT: floor(C); FIXED: floor(threshold)
-    uint32_t magic;       // ceil(2^28 / n)
-    int n_half;           // n / 2
+    int n, n_half;        // b*b and b*b/2
+    int wb;               // words per row of the bit image
     uint8_t* thres;
-    uint8_t* nbr;
-    uint2* trig;
-    uint32_t* trig_cnt;
+    uint32_t* bits;
+    uint2* raw;           // raw candidate list of the plane
+    uint32_t* raw_cnt;
     uint32_t* counters;
-    uint32_t cap_trig;
+    uint32_t cap_raw;
 };
 
-constexpr int LOCAL_TRIG = 192;   // candidates a workgroup can stage in LDS; more go straight to the global list
+__device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xFFu; }
 
-template <int RT, int MODE>
-__global__ __launch_bounds__(NT) void threshold_kernel(ThrArgs a) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    const int R = (RT >= 0) ? RT : a.R;
-    const int GW = TW + 2 * R + 2;              // gray tile width
-    const int GP = (GW + 3) & ~3;               // pitch
-    const int GH = TH + 2 * R + 2;
-    const int HP = TW + 2;                      // hsum pitch (u16)
-    uint8_t* g = lds;
-    uint16_t* hs = (uint16_t*)(lds + ((GP * GH + 15) & ~15));
-    uint8_t* bn = (uint8_t*)(hs + ((HP * GH + 7) & ~7));   // (TH+2) x (TW+2), pitch BP
-    const int BP = TW + 4;
+template <int R, int MODE>
+__global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
+    constexpr int RING = 2 * R + 1;
+    constexpr int NL = (R + 3) / 4;            // neighbour dwords needed on each side for the horizontal sums
+    constexpr bool PACKV = RING * RING * 255 < 65536;
     __shared__ uint32_t s_trig[LOCAL_TRIG];
     __shared__ uint32_t s_ntrig, s_base;
-    if (threadIdx.x == 0) s_ntrig = 0;
-
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int frame = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int W = a.width, H = a.height;
+    const int x = (int)blockIdx.x * STRIP_OUT - STRIP_HALO + 4 * lane;   // first pixel of this lane
+    const int ys = (int)blockIdx.y * SEG, ye = min(ys + SEG, H);
     const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
-    const int gx0 = x0 - R - 1, gy0 = y0 - R - 1;
-
-    // ---- stage gray tile (BORDER_REPLICATE by clamping)
-    const bool interior = gx0 >= 0 && gx0 + GP <= W && ((a.row_stride | (size_t)gx0 | (size_t)src) & 3) == 0;
-    if (interior) {
-        const int dw = GP / 4;
-        for (int i = tid; i < GH * dw; i += NT) {
-            int r = i / dw, c = i - r * dw;
-            int y = min(max(gy0 + r, 0), H - 1);
-            uint32_t v = *(const uint32_t*)(src + (size_t)y * a.row_stride + gx0 + c * 4);
-            *(uint32_t*)(g + r * GP + c * 4) = v;
-        }
-    } else {
-        for (int i = tid; i < GH * GW; i += NT) {
-            int r = i / GW, c = i - r * GW;
-            int y = min(max(gy0 + r, 0), H - 1), x = min(max(gx0 + c, 0), W - 1);
-            g[r * GP + c] = src[(size_t)y * a.row_stride + x];
-        }
-    }
-    __syncthreads();
-
-    // ---- horizontal box sums for columns x0-1 .. x0+TW
-    if (MODE == MODE_ADPT) {
-        for (int i = tid; i < GH * HP; i += NT) {
-            int r = i / HP, c = i - r * HP;
-            const uint8_t* p = g + r * GP + c;
-            int s = 0;
-            if (RT >= 0) {
-#pragma unroll
-                for (int k = 0; k <= 2 * RT; k++) s += p[k];
-            } else {
-                for (int k = 0; k <= 2 * R; k++) s += p[k];
-            }
-            hs[r * HP + c] = (uint16_t)s;
-        }
-        __syncthreads();
-    }
-
-    // ---- vertical sums, mean, threshold for rows y0-1 .. y0+TH, cols x0-1 .. x0+TW
-    for (int i = tid; i < (TH + 2) * HP; i += NT) {
-        int r = i / HP, c = i - r * HP;
-        int v = g[(r + R) * GP + c + R];
-        int thr;
-        if (MODE == MODE_ADPT) {
-            int s = 0;
-            if (RT >= 0) {
-#pragma unroll
-                for (int k = 0; k <= 2 * RT; k++) s += hs[(r + k) * HP + c];
-            } else {
-                for (int k = 0; k <= 2 * R; k++) s += hs[(r + k) * HP + c];
-            }
-            int mean = (int)(((uint64_t)(uint32_t)(s + a.n_half) * a.magic) >> 28);
-            thr = (v + a.idelta <= mean);
-        } else if (MODE == MODE_FIXED) {
-            thr = !(v > a.idelta);
-        } else {
-            thr = v != 0;
-        }
-        int x = x0 - 1 + c, y = y0 - 1 + r;
-        int inside = (x >= 1) & (x <= W - 2) & (y >= 1) & (y <= H - 2);
-        bn[r * BP + c] = (uint8_t)((thr & inside) | (thr << 1));
-    }
-    __syncthreads();
-
-    // ---- outputs: 4 pixels per thread-iteration
     const int plane = frame * a.nthr + a.t;
     uint8_t* tdst = a.thres + (size_t)plane * W * H;
-    uint8_t* ndst = a.nbr + (size_t)plane * W * H;
-    const bool can_dword = (W & 3) == 0;
-    for (int d = tid; d < TH * (TW / 4); d += NT) {
-        int r = d / (TW / 4), c4 = (d - r * (TW / 4)) * 4;
-        int y = y0 + r;
-        if (y >= H) continue;
-        uint32_t tpack = 0, npack = 0;
+    uint32_t* bdst = a.bits + (size_t)plane * a.wb * H;
+    if (lane == 0) s_ntrig = 0;
+    __syncthreads();
+
+    const bool whole = x >= 0 && x + 3 < W;                                   // all 4 pixels inside the image
+    const bool aligned = ((a.row_stride | (size_t)src) & 3) == 0;             // dword loads allowed
+    const bool out_lane = lane >= 4 && lane < 60 && x < W;
+    const bool word_lane = (lane & 7) == 4 && lane < 60 && x < W;
+    uint32_t insx = 0;                                                         // pixels with 1 <= x <= W-2
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int c = c4 + q, x = x0 + c;
-            const uint8_t* p = bn + (r + 1) * BP + (c + 1);
-            int e = p[1] & 1, ne = p[-BP + 1] & 1, n = p[-BP] & 1, nw = p[-BP - 1] & 1;
-            int w = p[-1] & 1, sw = p[BP - 1] & 1, s = p[BP] & 1, se = p[BP + 1] & 1;
-            int self = p[0];
-            uint32_t m = e | (ne << 1) | (n << 2) | (nw << 3) | (w << 4) | (sw << 5) | (s << 6) | (se << 7);
-            tpack |= ((self >> 1) ? 255u : 0u) << (8 * q);
-            npack |= m << (8 * q);
-            if (x < W) {
-                int b = self & 1;
-                int inside = (x >= 1) & (x <= W - 2) & (y >= 1) & (y <= H - 2);
-                int outer = b & !(w | nw | n | ne);
-                int hole = (!b) & inside & w & n;
-                if (outer) {
-                    // follow the run to the right: any set pixel 8-adjacent in the row above joins an earlier pixel
-                    for (int j = 1; c + 1 + j + 1 <= TW + 1; j++) {
-                        if (!(p[j] & 1)) break;
-                        if (p[-BP + j + 1] & 1) {
-                            outer = 0;
-                            break;
-                        }
-                    }
-                } else if (hole) {
-                    // follow the background run: a clear pixel directly above joins an earlier background pixel
-                    for (int j = 1; c + 1 + j <= TW + 1; j++) {
-                        if (p[j] & 1) break;
-                        if (!(p[-BP + j] & 1)) {
-                            hole = 0;
-                            break;
-                        }
+    for (int j = 0; j < 4; j++) insx |= (uint32_t)((x + j >= 1) && (x + j <= W - 2)) << j;
+    const int xc0 = min(max(x, 0), W - 1), xc1 = min(max(x + 1, 0), W - 1), xc2 = min(max(x + 2, 0), W - 1), xc3 = min(max(x + 3, 0), W - 1);
+
+    auto load_row = [&](int r) -> uint32_t {
+        const uint8_t* row = src + (size_t)min(max(r, 0), H - 1) * a.row_stride;   // BORDER_REPLICATE in y
+        if (whole && aligned) return *(const uint32_t*)(row + x);
+        return (uint32_t)row[xc0] | ((uint32_t)row[xc1] << 8) | ((uint32_t)row[xc2] << 16) | ((uint32_t)row[xc3] << 24);   // and in x
+    };
+
+    uint32_t G[RING], H01[RING], H23[RING];
+#pragma unroll
+    for (int k = 0; k < RING; k++) G[k] = 0, H01[k] = 0, H23[k] = 0;
+    uint32_t V01 = 0, V23 = 0;          // packed u16 pairs (PACKV) ...
+    uint32_t V0 = 0, V1 = 0, V2 = 0, V3 = 0;   // ... or four 32-bit sums
+    uint32_t Eup = 0;                   // 6-bit pattern (left px, own 4, right px) of the binary row above
+
+    const int r_begin = ys - 1 - R;     // first gray row; the first complete window is centred on row ys-1
+    const int r_end = ye - 1 + R;       // last gray row
+    for (int r0 = r_begin; r0 <= r_end; r0 += RING) {
+#pragma unroll
+        for (int k = 0; k < RING; k++) {
+            const int r = r0 + k;
+            if (r > r_end) break;
+            const uint32_t D0 = load_row(r);
+            uint32_t tbits = 0;         // raw threshold of the centre row, 4 bits
+            const int c = r - R;        // centre row of the window that ends at r
+            if (MODE == MODE_ADPT) {
+                // ---- horizontal box sums of the 4 pixels
+                uint32_t Dn[2 * NL + 1];
+                Dn[NL] = D0;
+#pragma unroll
+                for (int q = 1; q <= NL; q++) {
+                    Dn[NL - q] = __shfl_up(D0, q, 64);
+                    Dn[NL + q] = __shfl_down(D0, q, 64);
+                }
+                auto px = [&](int i) -> uint32_t {   // byte i of the row relative to this lane's first pixel, i in [-4NL, 4NL+3]
+                    const int q = i + 4 * NL;
+                    return byte_of(Dn[q >> 2], q & 3);
+                };
+                uint32_t s0 = 0;
+#pragma unroll
+                for (int i = -R; i <= R; i++) s0 += px(i);
+                const uint32_t s1 = s0 - px(-R) + px(R + 1);
+                const uint32_t s2 = s1 - px(1 - R) + px(R + 2);
+                const uint32_t s3 = s2 - px(2 - R) + px(R + 3);
+                const uint32_t h01 = s0 | (s1 << 16), h23 = s2 | (s3 << 16);
+                // ---- vertical running sums: row r enters, row r-RING leaves (it sits in the slot being overwritten)
+                if (PACKV) {
+                    V01 = V01 + h01 - H01[k];
+                    V23 = V23 + h23 - H23[k];
+                } else {
+                    V0 += (h01 & 0xFFFFu) - (H01[k] & 0xFFFFu), V1 += (h01 >> 16) - (H01[k] >> 16);
+                    V2 += (h23 & 0xFFFFu) - (H23[k] & 0xFFFFu), V3 += (h23 >> 16) - (H23[k] >> 16);
+                }
+                H01[k] = h01, H23[k] = h23, G[k] = D0;
+                if (r < r_begin + 2 * R) continue;   // window not complete yet
+                const uint32_t Gc = G[(k + RING - R) % RING];
+                const int v0 = PACKV ? (int)(V01 & 0xFFFFu) : (int)V0, v1 = PACKV ? (int)(V01 >> 16) : (int)V1;
+                const int v2 = PACKV ? (int)(V23 & 0xFFFFu) : (int)V2, v3 = PACKV ? (int)(V23 >> 16) : (int)V3;
+                tbits = (uint32_t)(((int)byte_of(Gc, 0) + a.idelta) * a.n <= v0 + a.n_half) |
+                        ((uint32_t)(((int)byte_of(Gc, 1) + a.idelta) * a.n <= v1 + a.n_half) << 1) |
+                        ((uint32_t)(((int)byte_of(Gc, 2) + a.idelta) * a.n <= v2 + a.n_half) << 2) |
+                        ((uint32_t)(((int)byte_of(Gc, 3) + a.idelta) * a.n <= v3 + a.n_half) << 3);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int v = (int)byte_of(D0, j);
+                    tbits |= (uint32_t)(MODE == MODE_FIXED ? !(v > a.idelta) : (v != 0)) << j;
+                }
+            }
+            // ---- binary row for contour purposes: frame cleared
+            const uint32_t B = (c >= 1 && c <= H - 2) ? (tbits & insx) : 0u;
+            const uint32_t left = (__shfl_up(B, 1, 64) >> 3) & 1u, right = __shfl_down(B, 1, 64) & 1u;
+            const uint32_t Emid = left | (B << 1) | (right << 5);
+            if (c >= ys) {   // c < ye by construction
+                if (MODE != MODE_BINARY && out_lane) {
+                    const uint32_t t4 = ((tbits * 0x00204081u) & 0x01010101u) * 255u;   // 4 bits -> 4 bytes of 0/255
+                    uint8_t* tp = tdst + (size_t)c * W + x;
+                    if (whole && (W & 3) == 0) {
+                        *(uint32_t*)tp = t4;
+                    } else {
+                        for (int j = 0; j < 4 && x + j < W; j++) tp[j] = (uint8_t)(t4 >> (8 * j));
                     }
                 }
-                if (outer | hole) {
-                    uint32_t e = ((uint32_t)hole << 31) | ((uint32_t)y << 16) | (uint32_t)x;
-                    uint32_t ls = atomicAdd(&s_ntrig, 1u);
+                // 32-px words: lanes 4,12,..,52 collect the nibbles of 8 lanes
+                uint32_t wv = B | (__shfl_down(B, 1, 64) << 4);
+                wv |= __shfl_down(wv, 2, 64) << 8;
+                wv |= __shfl_down(wv, 4, 64) << 16;
+                if (word_lane) bdst[(size_t)c * a.wb + (x >> 5)] = wv;
+                // border-start candidates of row c (rows c-1 and c)
+                const uint32_t self4 = B, w4 = Emid & 15u, nw4 = Eup & 15u, n4 = (Eup >> 1) & 15u, ne4 = (Eup >> 2) & 15u;
+                uint32_t outer4 = self4 & ~(w4 | nw4 | n4 | ne4);
+                uint32_t hole4 = ~self4 & w4 & n4 & insx;   // row c is inside (c >= ys >= 0; c <= H-2 checked below)
+                if (c > H - 2 || c < 1) hole4 = 0;
+                uint32_t cand = out_lane ? (outer4 | (hole4 << 4)) : 0u;
+                while (cand) {
+                    const int b = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    const uint32_t e = ((uint32_t)(b >> 2) << 31) | ((uint32_t)c << 16) | (uint32_t)(x + (b & 3));
+                    const uint32_t ls = atomicAdd(&s_ntrig, 1u);
                     if (ls < LOCAL_TRIG) {
                         s_trig[ls] = e;
                     } else {
-                        uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], 1u);
-                        if (slot < a.cap_trig)
-                            a.trig[(size_t)plane * a.cap_trig + slot] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+                        const uint32_t slot = atomicAdd(&a.raw_cnt[plane * TRIG_CNT_STRIDE], 1u);
+                        if (slot < a.cap_raw)
+                            a.raw[(size_t)plane * a.cap_raw + slot] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
                         else
                             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
                     }
                 }
             }
-        }
-        int x = x0 + c4;
-        size_t off = (size_t)y * W + x;
-        if (can_dword && x + 3 < W) {
-            if (MODE != MODE_BINARY) *(uint32_t*)(tdst + off) = tpack;
-            *(uint32_t*)(ndst + off) = npack;
-        } else {
-            for (int q = 0; q < 4 && x + q < W; q++) {
-                if (MODE != MODE_BINARY) tdst[off + q] = (uint8_t)(tpack >> (8 * q));
-                ndst[off + q] = (uint8_t)(npack >> (8 * q));
-            }
+            Eup = Emid;
         }
     }
-    // ---- flush the staged start candidates: one atomic per workgroup on the plane's own counter
+    // ---- flush the staged candidates: one atomic per wave on the plane's own counter
     __syncthreads();
     const uint32_t nl = min(s_ntrig, (uint32_t)LOCAL_TRIG);
     if (nl == 0) return;
-    if (tid == 0) s_base = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], nl);
+    if (lane == 0) s_base = atomicAdd(&a.raw_cnt[plane * TRIG_CNT_STRIDE], nl);
     __syncthreads();
     const uint32_t base = s_base;
-    for (uint32_t i = tid; i < nl; i += NT) {
-        uint32_t e = s_trig[i];
-        if (base + i < a.cap_trig)
-            a.trig[(size_t)plane * a.cap_trig + base + i] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+    for (uint32_t i = lane; i < nl; i += 64) {
+        const uint32_t e = s_trig[i];
+        if (base + i < a.cap_raw)
+            a.raw[(size_t)plane * a.cap_raw + base + i] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
         else
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
     }
 }
 
-static size_t lds_bytes(int R) {
-    int GW = TW + 2 * R + 2, GP = (GW + 3) & ~3, GH = TH + 2 * R + 2, HP = TW + 2;
-    size_t a = (size_t)((GP * GH + 15) & ~15);
-    size_t b = (size_t)((HP * GH + 7) & ~7) * 2;
-    size_t c = (size_t)(TH + 2) * (TW + 4);
-    return a + b + c;
+template <int R>
+static void launch_adpt(hipStream_t s, const ThrArgs& a, dim3 grid) {
+    hipLaunchKernelGGL((threshold_strip_kernel<R, MODE_ADPT>), grid, dim3(64), 0, s, a);
 }
 
-template <int MODE>
-static void launch_mode(hipStream_t s, ThrArgs& a, dim3 grid) {
-    size_t sh = lds_bytes(a.R);
-    if (MODE == MODE_ADPT && a.R == 3)
-        hipLaunchKernelGGL((threshold_kernel<3, MODE>), grid, dim3(NT), sh, s, a);
-    else if (MODE != MODE_ADPT)
-        hipLaunchKernelGGL((threshold_kernel<0, MODE>), grid, dim3(NT), sh, s, a);
-    else
-        hipLaunchKernelGGL((threshold_kernel<-1, MODE>), grid, dim3(NT), sh, s, a);
+static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const Buffers& b, int nthr, int t) {
+    a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
+    a.width = g.width, a.height = g.height, a.nthr = nthr, a.t = t;
+    a.wb = bits_pitch(g.width);
+    a.thres = b.thres, a.bits = b.bits, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters, a.cap_raw = b.cap_raw;
+    a.idelta = 0, a.n = 1, a.n_half = 0;
 }
 
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
-    dim3 grid((g.width + TW - 1) / TW, (g.height + TH - 1) / TH, nframes);
+    dim3 grid((g.width + STRIP_OUT - 1) / STRIP_OUT, (g.height + SEG - 1) / SEG, nframes);
     for (int t = 0; t < p.nthr; t++) {
         ThrArgs a;
-        a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
-        a.width = g.width, a.height = g.height, a.nthr = p.nthr, a.t = t;
-        a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
+        fill_args(a, gray, g, b, p.nthr, t);
         if (p.thres_method == ARUCOHIP_THRES_FIXED) {
-            a.R = 0, a.idelta = (int)floor(p.p1[t]), a.magic = 0, a.n_half = 0;
-            launch_mode<MODE_FIXED>(s, a, grid);
-        } else {
-            int n = p.block[t] * p.block[t];
-            a.R = p.block[t] / 2, a.idelta = p.idelta, a.n_half = n / 2;
-            a.magic = (uint32_t)(((1ull << 28) + n - 1) / n);
-            launch_mode<MODE_ADPT>(s, a, grid);
+            a.idelta = (int)floor(p.p1[t]);
+            hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_FIXED>), grid, dim3(64), 0, s, a);
+            continue;
+        }
+        a.n = p.block[t] * p.block[t], a.n_half = a.n / 2, a.idelta = p.idelta;
+        switch (p.block[t] / 2) {
+            case 1: launch_adpt<1>(s, a, grid); break;
+            case 2: launch_adpt<2>(s, a, grid); break;
+            case 3: launch_adpt<3>(s, a, grid); break;
+            case 4: launch_adpt<4>(s, a, grid); break;
+            case 5: launch_adpt<5>(s, a, grid); break;
+            case 6: launch_adpt<6>(s, a, grid); break;
+            case 7: launch_adpt<7>(s, a, grid); break;
+            case 8: launch_adpt<8>(s, a, grid); break;
+            case 9: launch_adpt<9>(s, a, grid); break;
+            case 10: launch_adpt<10>(s, a, grid); break;
+            case 11: launch_adpt<11>(s, a, grid); break;
+            case 12: launch_adpt<12>(s, a, grid); break;
+            case 13: launch_adpt<13>(s, a, grid); break;
+            case 14: launch_adpt<14>(s, a, grid); break;
+            default: launch_adpt<15>(s, a, grid); break;
         }
     }
 }
 
-// detectRectangles on a caller-supplied thresholded image (markerdetector.h:261): only masks + candidates.
+// detectRectangles on a caller-supplied thresholded image (markerdetector.h:261): only the bit image + candidates.
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b) {
-    dim3 grid((g.width + TW - 1) / TW, (g.height + TH - 1) / TH, nframes);
+    dim3 grid((g.width + STRIP_OUT - 1) / STRIP_OUT, (g.height + SEG - 1) / SEG, nframes);
     ThrArgs a;
-    a.gray = thres_in, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
-    a.width = g.width, a.height = g.height, a.nthr = 1, a.t = 0;
-    a.thres = b.thres, a.nbr = b.nbr, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
-    a.R = 0, a.idelta = 0, a.magic = 0, a.n_half = 0;
-    launch_mode<MODE_BINARY>(s, a, grid);
+    fill_args(a, thres_in, g, b, 1, 0);
+    hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_BINARY>), grid, dim3(64), 0, s, a);
 }
 
 }  // namespace ah
