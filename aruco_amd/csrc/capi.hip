@@ -167,7 +167,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     const size_t F = lim->max_batch, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
-    b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame / 4, 4096);
+    b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
     b.cap_cdesc = (uint32_t)std::min<size_t>(P * lim->contours_per_frame, 0xFFFFFFF0u);
     b.cap_pool = (uint32_t)std::min<size_t>(P * lim->points_per_frame, 0xFFFFFFF0u);
     b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);

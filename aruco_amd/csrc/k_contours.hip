@@ -48,15 +48,28 @@ __device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
 
 __device__ __forceinline__ uint64_t load_bits64(const uint32_t* p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 32); }
 
-// 8-neighbour occupancy byte of pixel (x,y) from the bit image: bit d = neighbour in direction d is set.
-__device__ __forceinline__ uint32_t nbr_mask(const uint32_t* bits, int wb, int x, int y) {
-    const int w = (x - 1) >> 5, sh = (x - 1) & 31;
-    const uint32_t* r = bits + (size_t)(y - 1) * wb + w;
-    const uint32_t up = (uint32_t)(load_bits64(r) >> sh) & 7u;
-    const uint32_t mid = (uint32_t)(load_bits64(r + wb) >> sh) & 7u;
-    const uint32_t dn = (uint32_t)(load_bits64(r + 2 * wb) >> sh) & 7u;
+// Packed pixel position: y << 16 | x. A step in direction d adds DPOS(d); raster order is the integer order.
+__device__ __forceinline__ uint32_t dpos(int d) {
+    // nibble d of the table = (dy+1) << 2 | (dx+1)
+    const uint32_t nib = (0xA9840126u >> (4 * d)) & 15u;
+    return ((nib >> 2) << 16) + (nib & 3u) - 65537u;
+}
+
+// 8-neighbour occupancy byte of the pixel at packed position `pos` from the bit image: bit d = neighbour d is set.
+// Three 8-byte reads (rows y-1, y, y+1, words (x-1)>>5 and the next one), one funnel shift each.
+__device__ __forceinline__ uint32_t nbr_mask_pos(const uint32_t* __restrict__ bits, int wb, uint32_t pos) {
+    const uint32_t xm = (pos & 0xFFFFu) - 1u, y = pos >> 16;
+    const uint32_t sh = xm & 31u;
+    const uint32_t* r = bits + (y - 1u) * (uint32_t)wb + (xm >> 5);
+    const uint32_t a0 = r[0], a1 = r[1], b0 = r[wb], b1 = r[wb + 1], c0 = r[2 * wb], c1 = r[2 * wb + 1];
+    const uint32_t up = __builtin_amdgcn_alignbit(a1, a0, sh) & 7u;
+    const uint32_t mid = __builtin_amdgcn_alignbit(b1, b0, sh) & 7u;
+    const uint32_t dn = __builtin_amdgcn_alignbit(c1, c0, sh) & 7u;
     // up = NW,N,NE  mid = W,self,E  dn = SW,S,SE (bit 0..2)  ->  E,NE,N,NW,W,SW,S,SE (bit 0..7)
-    return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
+    return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
+}
+__device__ __forceinline__ uint32_t nbr_mask(const uint32_t* bits, int wb, int x, int y) {
+    return nbr_mask_pos(bits, wb, ((uint32_t)y << 16) | (uint32_t)x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -75,14 +88,16 @@ struct FilterArgs {
     int wb, height;
 };
 
+// Survivors go to two lists per plane (outer starts in the first half of trig[plane], hole starts in the second half)
+// so that a walker wavefront follows only one kind of border.
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
-    __shared__ uint2 s_keep[256];
-    __shared__ uint32_t s_n, s_base;
+    __shared__ uint2 s_keep[2][256];
+    __shared__ uint32_t s_n[2], s_base[2];
     const int plane = blockIdx.y;
     const uint32_t nraw = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
     const uint32_t* bits = a.bits + (size_t)plane * a.wb * a.height;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nraw; i0 += gridDim.x * blockDim.x) {
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t i = i0 + threadIdx.x;
         if (i < nraw) {
@@ -105,17 +120,17 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
                 const uint64_t m = hi >= 1 ? (((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull))) & ~1ull) : 0ull;
                 keep = (~up & m) == 0;
             }
-            if (keep) s_keep[atomicAdd(&s_n, 1u)] = t;
+            if (keep) s_keep[hole][atomicAdd(&s_n[hole], 1u)] = t;
         }
         __syncthreads();
-        const uint32_t n = s_n;
-        if (n) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE], n);
-            __syncthreads();
-            if (threadIdx.x < n) {
-                const uint32_t slot = s_base + threadIdx.x;
-                if (slot < a.cap_trig)
-                    a.trig[(size_t)plane * a.cap_trig + slot] = s_keep[threadIdx.x];
+        if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + threadIdx.x], s_n[threadIdx.x]);
+        __syncthreads();
+        const uint32_t half = a.cap_trig / 2;
+        for (int kind = 0; kind < 2; kind++) {
+            if (threadIdx.x < s_n[kind]) {
+                const uint32_t slot = s_base[kind] + threadIdx.x;
+                if (slot < half)
+                    a.trig[(size_t)plane * a.cap_trig + kind * half + slot] = s_keep[kind][threadIdx.x];
                 else
                     atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
             }
@@ -153,72 +168,84 @@ struct WalkArgs {
 
 // Kernel 2: one lane per start candidate. Workgroups are dealt round-robin over the 8 XCDs, so the linear block id is
 // unpacked such that all workgroups of one plane share an XCD and its L2 keeps that plane's 1-bit image (W*H/8 bytes).
-__global__ __launch_bounds__(256) void walker_kernel(WalkArgs a) {
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
-    if (plane >= a.nplanes) return;
-    const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE], a.cap_trig);
-    const int W = a.width;
-    const uint32_t* bits = a.bits + (size_t)plane * a.wb * a.height;
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < ntrig; i += WALK_BLOCKS * blockDim.x) {
-        uint2 t = a.trig[(size_t)plane * a.cap_trig + i];
-        const int hole = (int)(t.x & 1);
-        const int tx = (int)(t.y & 0xFFFF), ty = (int)(t.y >> 16);
-        const int x0 = tx - hole, y0 = ty;
-        uint32_t m = nbr_mask(bits, a.wb, x0, y0);
-        int s = first_dir(m, hole ? 0 : 4);
+// The first half of a plane's workgroups follows outer candidates, the second half hole candidates.
+template <bool HOLE>
+__device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chunk, int nchunks) {
+    const uint32_t half = a.cap_trig / 2;
+    const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
+    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const uint2* list = a.trig + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
+    uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
+    const uint32_t nmax = (uint32_t)a.max_contour;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < ntrig; i += nchunks * blockDim.x) {
+        const uint32_t tkey = list[i].y;              // y << 16 | x of the scan transition
+        const uint32_t pos0 = tkey - (HOLE ? 1u : 0u);
+        uint32_t m = nbr_mask_pos(bits, a.wb, pos0);
+        int s = first_dir(m, HOLE ? 0 : 4);
         if (s < 0) continue;  // isolated pixel: 1 point, never passes the size filter
-        const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
-        int x = x0, y = y0, n = 0;
+        const uint32_t pos1 = pos0 + dpos(s);
+        uint32_t pos = pos0, n = 0;
         bool ok = true;
-        uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
         for (;;) {
-            if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(x, y, s);
-            uint32_t ex;
-            int d = next_dir(m, s, &ex);
-            if (hole) {
-                // background 4-neighbours examined from (x,y)
-                if (((ex & 1u) && raster_lt(y, x + 1, ty, tx)) || ((ex & 4u) && raster_lt(y - 1, x, ty, tx)) ||
-                    ((ex & 16u) && raster_lt(y, x - 1, ty, tx)) || ((ex & 64u) && raster_lt(y + 1, x, ty, tx))) {
-                    ok = false;
-                    break;
-                }
-            } else if (raster_lt(y, x, y0, x0)) {
+            if ((n & (CK - 1)) == 0) ck[n / CK] = (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28);
+            // first set neighbour counter-clockwise after the direction of the previous pixel
+            const uint32_t sh = (uint32_t)(s + 1) & 7u;
+            const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
+            const int k = __builtin_ctz(rot | 0x100u);
+            const int d = (int)((sh + (uint32_t)k) & 7u);
+            bool bad;
+            if (HOLE) {
+                // smallest background 4-neighbour examined from this pixel (N < W < E < S in raster order)
+                uint32_t ex = ((1u << k) - 1u) << sh;
+                ex |= ex >> 8;
+                const uint32_t small = (ex & 4u) ? pos - 65536u : (ex & 16u) ? pos - 1u : (ex & 1u) ? pos + 1u : (ex & 64u) ? pos + 65536u : 0xFFFFFFFFu;
+                bad = small < tkey;
+            } else {
+                bad = pos < pos0;
+            }
+            ++n;
+            if (bad | (n >= nmax)) {
                 ok = false;
                 break;
             }
-            if (++n >= a.max_contour) {
-                ok = false;
-                break;
-            }
-            int nx = x + dir_dx(d), ny = y + dir_dy(d);
-            if (nx == x0 && ny == y0 && x == x1 && y == y1) break;
-            x = nx, y = ny;
+            const uint32_t npos = pos + dpos(d);
+            if (npos == pos0 && pos == pos1) break;
+            pos = npos;
             s = (d + 4) & 7;
-            m = nbr_mask(bits, a.wb, x, y);
+            m = nbr_mask_pos(bits, a.wb, pos);
         }
-        if (!ok || n <= a.min_contour) continue;
-        const int ncp = (n + CK - 1) / CK;
+        if (!ok || (int)n <= a.min_contour) continue;
+        const uint32_t ncp = (n + CK - 1) / CK;
         uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
-        uint32_t off = atomicAdd(&a.counters[CNT_POOL], (uint32_t)(n + ncp));
+        uint32_t off = atomicAdd(&a.counters[CNT_POOL], n + ncp);
         if (slot >= a.cap_cdesc) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
             continue;
         }
-        if (off + (uint32_t)(n + ncp) > a.cap_pool) {
+        if (off + n + ncp > a.cap_pool) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
             n = 0;  // keeps list consistent; a zero-length contour is ignored downstream
         } else {
             uint32_t* dst = (uint32_t*)(a.pool + off);
-            for (int k = 0; k < ncp; k++) dst[k] = ck[k];
-            off += (uint32_t)ncp;   // points follow the checkpoints
+            for (uint32_t q = 0; q < ncp; q++) dst[q] = ck[q];
+            off += ncp;   // points follow the checkpoints
         }
         ContourDesc cd;
-        cd.plane = plane, cd.x0 = (int16_t)x0, cd.y0 = (int16_t)y0, cd.hole = hole, cd.n = n;
-        cd.key = (uint32_t)ty * (uint32_t)W + (uint32_t)tx;
+        cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = HOLE ? 1 : 0, cd.n = (int)n;
+        cd.key = (tkey >> 16) * (uint32_t)a.width + (tkey & 0xFFFFu);
         cd.pool_off = off;
         a.cdesc[slot] = cd;
     }
+}
+
+__global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
+    if (plane >= a.nplanes) return;
+    if (chunk < WALK_BLOCKS / 2)
+        walk_list<false>(a, plane, chunk, WALK_BLOCKS / 2);
+    else
+        walk_list<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2);
 }
 
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
@@ -276,16 +303,18 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
             const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
             for (int k = lane; k < ncp; k += WAVE) {
                 const uint32_t c = ckp[k];
-                int x = (int)(c & 0x3FFFu), y = (int)((c >> 14) & 0x3FFFu), s = (int)(c >> 28);
-                uint32_t m = nbr_mask(bits, a.wb, x, y);
+                uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
+                int s = (int)(c >> 28);
+                uint32_t m = nbr_mask_pos(bits, a.wb, pos);
                 const int n0 = k * CK, n1 = min(n0 + CK, count);
                 for (int n = n0; n < n1; n++) {
-                    uint32_t ex;
-                    int d = next_dir(m, s, &ex);
-                    P[n] = make_short2((short)x, (short)y);
-                    x += dir_dx(d), y += dir_dy(d);
+                    const uint32_t sh = (uint32_t)(s + 1) & 7u;
+                    const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
+                    const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
+                    P[n] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
+                    pos += dpos(d);
                     s = (d + 4) & 7;
-                    if (n + 1 < n1) m = nbr_mask(bits, a.wb, x, y);
+                    if (n + 1 < n1) m = nbr_mask_pos(bits, a.wb, pos);
                 }
             }
         }
