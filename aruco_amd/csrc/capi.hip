@@ -41,6 +41,7 @@ struct arucohip_handle {
     size_t gray_bytes = 0;
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
     size_t bits_bytes = 0;
+    size_t patch_bytes = 0;           // capacity of buf.patches
     int bits_w = 0, bits_h = 0;       // geometry the bit image was last written with (pad words depend on it)
     // pinned host staging
     arucohip_marker_t* h_markers = nullptr;
@@ -125,8 +126,8 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
 static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
     hipFree(h->buf.thres), hipFree(h->buf.bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
-    hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
+    hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -188,6 +189,11 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
     ALLOC(b.cands, F * b.cap_cands * sizeof(Cand));
     ALLOC(b.ncands, F * sizeof(int32_t));
+    b.cap_flat = (uint32_t)std::min<size_t>(F * (size_t)std::min(b.cap_cands, 96), 65535u * 16u);
+    ALLOC(b.cand_list, (size_t)b.cap_flat * sizeof(uint32_t));
+    ALLOC(b.iM, (size_t)b.cap_flat * 9 * sizeof(double));
+    ALLOC(b.hist, (size_t)b.cap_flat * 256 * sizeof(uint16_t));
+    ALLOC(b.othr, (size_t)b.cap_flat * sizeof(int32_t));
     ALLOC(b.markers, F * b.cap_markers * sizeof(arucohip_marker_t));
     ALLOC(b.nmarkers, F * sizeof(int32_t));
     ALLOC(b.counters, (CNT_FIXED + F) * sizeof(uint32_t));
@@ -358,9 +364,20 @@ static int ensure_bits_geometry(arucohip_handle* h, int W, int H) {
     return ARUCOHIP_OK;
 }
 
+// canonical patches of the decode stage: cap_flat * warp_size^2 bytes
+static int ensure_patches(arucohip_handle* h, const DetectParams& dp) {
+    size_t need = (size_t)h->buf.cap_flat * dp.warp_size * dp.warp_size;
+    if (need <= h->patch_bytes) return ARUCOHIP_OK;
+    if (h->buf.patches) HIPCHK(h, hipFree(h->buf.patches));
+    h->buf.patches = nullptr, h->patch_bytes = 0;
+    HIPCHK(h, hipMalloc((void**)&h->buf.patches, need));
+    h->patch_bytes = need;
+    return ARUCOHIP_OK;
+}
+
 // the walkers keep one checkpoint ring per lane in HBM; (re)size it for this batch
 static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
-    size_t need = (size_t)((nplanes + 7) / 8) * 8 * WALK_BLOCKS * 64 * ((dp.max_contour + 31) / 32);
+    size_t need = (size_t)((nplanes + 7) / 8) * 8 * WALK_BLOCKS * 64 * ((dp.max_contour + 15) / 16);
     if (need <= h->scratch_words) return ARUCOHIP_OK;
     if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
     h->buf.walk_scratch = nullptr, h->scratch_words = 0;
@@ -384,6 +401,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         int rc_ = ensure_walk_scratch(h, nframes * dp.nthr, dp);
         if (rc_) return rc_;
         if ((rc_ = ensure_bits_geometry(h, g.width, g.height))) return rc_;
+        if ((rc_ = ensure_patches(h, dp))) return rc_;
     }
     HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));

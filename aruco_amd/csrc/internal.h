@@ -30,6 +30,7 @@ enum Counter {
     CNT_CDESC = 1,     // number of contour descriptors
     CNT_POOL = 2,      // contour points allocated
     CNT_STATUS = 3,    // overflow bit flags
+    CNT_NCAND = 5,     // entries of the flat candidate list (all frames)
     CNT_FIXED = 8      // per-frame counters follow: [CNT_FIXED + f] = quads of frame f
 };
 
@@ -107,6 +108,12 @@ struct Buffers {
     Quad* quads;
     Cand* cands;
     int32_t* ncands;       // [F]
+    uint32_t* cand_list;   // flat list over all frames: frame << 16 | index, counters[CNT_NCAND] entries
+    double* iM;            // [cap_flat][9] inverse homographies
+    uint16_t* hist;        // [256][cap_flat] patch histograms
+    int32_t* othr;         // [cap_flat] Otsu thresholds
+    uint8_t* patches;      // [cap_flat][warp_size^2] canonical patches
+    uint32_t cap_flat;
     arucohip_marker_t* markers;
     int32_t* nmarkers;     // [F]
     uint32_t* counters;

@@ -146,7 +146,7 @@ void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers
     hipLaunchKernelGGL(filter_kernel, dim3(8, nplanes), dim3(256), 0, s, a);
 }
 
-constexpr int CK = 32;   // border steps between two checkpoints
+constexpr int CK = 16;   // border steps between two checkpoints
 
 // A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
 __device__ __forceinline__ uint32_t pack_ck(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)s << 28); }
@@ -491,6 +491,8 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
 struct FrameArgs {
     const Quad* quads;
     Cand* cands;
+    uint32_t* cand_list;
+    uint32_t cap_flat;
     int32_t* ncands;
     uint32_t* counters;
     int cap_quads, cap_cands;
@@ -573,12 +575,23 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
             C[n++] = c;
         }
         a.ncands[frame] = n;
+        // flat list for the decode kernels (order across frames is irrelevant)
+        if (n > 0) {
+            uint32_t base = atomicAdd(&a.counters[CNT_NCAND], (uint32_t)n);
+            for (int i = 0; i < n; i++) {
+                if (base + i < a.cap_flat)
+                    a.cand_list[base + i] = ((uint32_t)frame << 16) | (uint32_t)i;
+                else
+                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CAND_OVERFLOW);
+            }
+        }
     }
 }
 
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     FrameArgs a;
     a.quads = b.quads, a.cands = b.cands, a.ncands = b.ncands, a.counters = b.counters;
+    a.cand_list = b.cand_list, a.cap_flat = b.cap_flat;
     a.cap_quads = b.cap_quads, a.cap_cands = b.cap_cands;
     hipLaunchKernelGGL(frame_candidates_kernel, dim3(nframes), dim3(64), 0, s, a);
 }

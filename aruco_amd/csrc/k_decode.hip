@@ -9,6 +9,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <algorithm>
+
 #include "internal.h"
 
 namespace ah {
@@ -116,117 +118,241 @@ __device__ static int hamm_dist(const uint8_t b[5][5]) {
     return dist;
 }
 
+// The decode stage is four small kernels so that the serial double-precision parts (8x8 homography solve, 256-bin Otsu
+// sweep) run one candidate per LANE while the pixel work (56x56 gather, histogram, cell counts) runs one candidate per
+// WAVEFRONT. Candidates of all frames are addressed through the flat list the frame kernel appended to.
 struct DecodeArgs {
     const uint8_t* gray;
     size_t row_stride, frame_stride;
     int width, height, ws;
     Cand* cands;
-    const int32_t* ncands;
     int cap_cands;
+    const uint32_t* cand_list;   // frame << 16 | index
+    const uint32_t* counters;    // [CNT_NCAND] = entries in cand_list
+    uint32_t cap_flat;
+    double* iM;                  // [cap_flat][9]
+    uint16_t* hist;              // [256][cap_flat]
+    int32_t* othr;               // [cap_flat]
+    uint8_t* patches;            // [cap_flat][ws*ws]
 };
 
-__global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
-    extern __shared__ __align__(16) uint8_t patch[];   // ws*ws bytes
+// 5a: one lane per candidate — inverse homography. The 8x8 system lives in LDS, element-major so that the 64 lanes of a
+// wave never collide on a bank (index k of lane l at k*64 + l).
+struct LaneMat {
+    double* base;
+    int lane;
+    __device__ __forceinline__ double& operator[](int k) const { return base[k * 64 + lane]; }
+};
+
+__global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
+    __shared__ double sA[64 * 64], sb[8 * 64];
+    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
+    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t e = a.cand_list[idx];
+    const Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
+    LaneMat A{sA, (int)threadIdx.x}, b{sb, (int)threadIdx.x};
+    const double d = (double)(float)(a.ws - 1);
+    const double dxs[4] = {0, d, d, 0}, dys[4] = {0, 0, d, d};
+    for (int i = 0; i < 64; i++) A[i] = 0;
+    for (int i = 0; i < 4; i++) {
+        const double sx = (double)(float)cand->qx[i], sy = (double)(float)cand->qy[i], dx = dxs[i], dy = dys[i];
+        const int r0 = i * 8, r1 = (i + 4) * 8;
+        A[r0 + 0] = sx, A[r1 + 3] = sx;
+        A[r0 + 1] = sy, A[r1 + 4] = sy;
+        A[r0 + 2] = 1, A[r1 + 5] = 1;
+        A[r0 + 6] = -sx * dx;
+        A[r0 + 7] = -sy * dx;
+        A[r1 + 6] = -sx * dy;
+        A[r1 + 7] = -sy * dy;
+        b[i] = dx;
+        b[i + 4] = dy;
+    }
+    // Gaussian elimination with partial pivoting, same operation order as the oracle
+    bool ok = true;
+    for (int c = 0; c < 8 && ok; c++) {
+        int piv = c;
+        double best = fabs(A[c * 8 + c]);
+        for (int r = c + 1; r < 8; r++) {
+            double v = fabs(A[r * 8 + c]);
+            if (v > best) best = v, piv = r;
+        }
+        if (best == 0) {
+            ok = false;
+            break;
+        }
+        if (piv != c) {
+            for (int k = 0; k < 8; k++) {
+                double t = A[c * 8 + k];
+                A[c * 8 + k] = A[piv * 8 + k];
+                A[piv * 8 + k] = t;
+            }
+            double t = b[c];
+            b[c] = b[piv];
+            b[piv] = t;
+        }
+        const double inv = 1.0 / A[c * 8 + c];
+        for (int r = c + 1; r < 8; r++) {
+            const double f = A[r * 8 + c] * inv;
+            if (f == 0) continue;
+            for (int k = c; k < 8; k++) A[r * 8 + k] -= f * A[c * 8 + k];
+            b[r] -= f * b[c];
+        }
+    }
+    double m[9];
+    if (ok) {
+        for (int r = 7; r >= 0; r--) {
+            double sacc = b[r];
+            for (int k = r + 1; k < 8; k++) sacc -= A[r * 8 + k] * b[k];
+            b[r] = sacc / A[r * 8 + r];
+        }
+        for (int i = 0; i < 8; i++) m[i] = b[i];
+    } else {
+        for (int i = 0; i < 8; i++) m[i] = 0;
+    }
+    m[8] = 1.0;
+    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    det = det != 0 ? 1. / det : 0;
+    double* iM = a.iM + (size_t)idx * 9;
+    iM[0] = (m[4] * m[8] - m[5] * m[7]) * det;
+    iM[1] = (m[2] * m[7] - m[1] * m[8]) * det;
+    iM[2] = (m[1] * m[5] - m[2] * m[4]) * det;
+    iM[3] = (m[5] * m[6] - m[3] * m[8]) * det;
+    iM[4] = (m[0] * m[8] - m[2] * m[6]) * det;
+    iM[5] = (m[2] * m[3] - m[0] * m[5]) * det;
+    iM[6] = (m[3] * m[7] - m[4] * m[6]) * det;
+    iM[7] = (m[1] * m[6] - m[0] * m[7]) * det;
+    iM[8] = (m[0] * m[4] - m[1] * m[3]) * det;
+}
+
+// 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram
+__global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     __shared__ int hist[256];
-    __shared__ double sA[64], sb[8], siM[9];
-    __shared__ int s_thr;
-    __shared__ uint8_t s_cell[49];
-    const int frame = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= a.ncands[frame]) return;
-    Cand* cand = a.cands + (size_t)frame * a.cap_cands + ci;
-    const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
-    const int ws = a.ws, npx = ws * ws;
-    for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
-    if (lane == 0) {
-        float q[8];
-        for (int k = 0; k < 4; k++) q[2 * k] = (float)cand->qx[k], q[2 * k + 1] = (float)cand->qy[k];
-        inverse_homography(q, ws, sA, sb, siM);
-    }
-    __syncthreads();
-    for (int i = lane; i < npx; i += WAVE) {
-        int y = i / ws, x = i - y * ws;
-        uint8_t v = warp_pixel(src, a.width, a.height, a.row_stride, siM, x, y);
-        patch[i] = v;
-        atomicAdd(&hist[v], 1);
-    }
-    __syncthreads();
-    if (lane == 0) {  // getThreshVal_Otsu_8u
-        double mu = 0, scale = 1. / npx;
-        for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
-        mu *= scale;
-        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-        for (int i = 0; i < 256; i++) {
-            double p_i = hist[i] * scale;
-            mu1 *= q1;
-            q1 += p_i;
-            double q2 = 1. - q1;
-            if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
-            mu1 = (mu1 + i * p_i) / q1;
-            double mu2 = (mu - q1 * mu1) / q2;
-            double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-            if (sigma > max_sigma) {
-                max_sigma = sigma;
-                max_val = i;
-            }
+    __shared__ double siM[9];
+    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
+    const int lane = threadIdx.x;
+    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        __syncthreads();
+        const uint32_t e = a.cand_list[idx];
+        const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
+        for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
+        if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
+        __syncthreads();
+        const int ws = a.ws, npx = ws * ws;
+        uint8_t* patch = a.patches + (size_t)idx * npx;
+        for (int i = lane; i < npx; i += WAVE) {
+            int y = i / ws, x = i - y * ws;
+            const uint8_t v = warp_pixel(src, a.width, a.height, a.row_stride, siM, x, y);
+            patch[i] = v;
+            atomicAdd(&hist[v], 1);
         }
-        s_thr = (int)max_val;
+        __syncthreads();
+        for (int i = lane; i < 256; i += WAVE) a.hist[(size_t)i * a.cap_flat + idx] = (uint16_t)hist[i];
     }
-    __syncthreads();
-    const int thr = s_thr, sw = ws / 7;
-    if (lane < 49) {  // 7x7 cells: white iff more than half of the pixels exceed the Otsu threshold
-        int cy = lane / 7, cx = lane - cy * 7, cnt = 0;
-        for (int y = 0; y < sw; y++)
-            for (int x = 0; x < sw; x++) cnt += patch[(cy * sw + y) * ws + cx * sw + x] > thr;
-        s_cell[lane] = cnt > (sw * sw) / 2;
+}
+
+// 5c: one lane per candidate — getThreshVal_Otsu_8u, strictly sequential in double like the reference
+__global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
+    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
+    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n) return;
+    const int npx = a.ws * a.ws;
+    const uint16_t* h = a.hist + idx;
+    double mu = 0, scale = 1. / npx;
+    for (int i = 0; i < 256; i++) mu += i * (double)h[(size_t)i * a.cap_flat];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        double p_i = h[(size_t)i * a.cap_flat] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        double q2 = 1. - q1;
+        if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        double mu2 = (mu - q1 * mu1) / q2;
+        double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
     }
-    __syncthreads();
-    if (lane == 0) {
-        int id = -1, nrot = 0;
-        bool border_ok = true;
-        for (int y = 0; y < 7 && border_ok; y++) {
-            int inc = (y == 0 || y == 6) ? 1 : 6;
-            for (int x = 0; x < 7; x += inc)
-                if (s_cell[y * 7 + x]) {
-                    border_ok = false;
-                    break;
+    a.othr[idx] = (int)max_val;
+}
+
+// 5d: one wavefront per candidate — 7x7 cell votes on the binarised patch and the 5x5 Hamming decode
+__global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
+    __shared__ int s_cnt[49];
+    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
+    const int lane = threadIdx.x;
+    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        __syncthreads();
+        const uint32_t e = a.cand_list[idx];
+        Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
+        const int ws = a.ws, sw = ws / 7, thr = a.othr[idx];
+        const uint8_t* patch = a.patches + (size_t)idx * ws * ws;
+        if (lane < 49) {   // cell (cy,cx): white iff more than half of its pixels exceed the Otsu threshold
+            const int cy = lane / 7, cx = lane - cy * 7;
+            int cnt = 0;
+            for (int y = 0; y < sw; y++)
+                for (int x = 0; x < sw; x++) cnt += patch[(cy * sw + y) * ws + cx * sw + x] > thr;
+            s_cnt[lane] = cnt;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int id = -1, nrot = 0;
+            const int half = (sw * sw) / 2;
+            bool border_ok = true;
+            for (int y = 0; y < 7 && border_ok; y++) {
+                int inc = (y == 0 || y == 6) ? 1 : 6;
+                for (int x = 0; x < 7; x += inc)
+                    if (s_cnt[y * 7 + x] > half) {
+                        border_ok = false;
+                        break;
+                    }
+            }
+            if (border_ok) {
+                uint8_t rot[2][5][5];
+                for (int y = 0; y < 5; y++)
+                    for (int x = 0; x < 5; x++) rot[0][y][x] = s_cnt[(y + 1) * 7 + x + 1] > half;
+                int min_dist = hamm_dist(rot[0]);
+                uint8_t best[5][5];
+                for (int y = 0; y < 5; y++)
+                    for (int x = 0; x < 5; x++) best[y][x] = rot[0][y][x];
+                int cur = 0;
+                for (int r = 1; r < 4; r++) {
+                    int nxt = cur ^ 1;
+                    for (int i = 0; i < 5; i++)
+                        for (int j = 0; j < 5; j++) rot[nxt][i][j] = rot[cur][5 - j - 1][i];
+                    cur = nxt;
+                    int dd = hamm_dist(rot[cur]);
+                    if (dd < min_dist) {
+                        min_dist = dd, nrot = r;
+                        for (int y = 0; y < 5; y++)
+                            for (int x = 0; x < 5; x++) best[y][x] = rot[cur][y][x];
+                    }
                 }
-        }
-        if (border_ok) {
-            uint8_t rot[2][5][5];
-            for (int y = 0; y < 5; y++)
-                for (int x = 0; x < 5; x++) rot[0][y][x] = s_cell[(y + 1) * 7 + x + 1];
-            int min_dist = hamm_dist(rot[0]);
-            uint8_t best[5][5];
-            for (int y = 0; y < 5; y++)
-                for (int x = 0; x < 5; x++) best[y][x] = rot[0][y][x];
-            int cur = 0;
-            for (int r = 1; r < 4; r++) {
-                int nxt = cur ^ 1;
-                for (int i = 0; i < 5; i++)
-                    for (int j = 0; j < 5; j++) rot[nxt][i][j] = rot[cur][5 - j - 1][i];
-                cur = nxt;
-                int d = hamm_dist(rot[cur]);
-                if (d < min_dist) {
-                    min_dist = d, nrot = r;
-                    for (int y = 0; y < 5; y++)
-                        for (int x = 0; x < 5; x++) best[y][x] = rot[cur][y][x];
+                if (min_dist == 0) {
+                    id = 0;
+                    for (int y = 0; y < 5; y++) id |= (best[y][1] << 1 | best[y][3]) << 2 * (4 - y);
                 }
             }
-            if (min_dist == 0) {
-                id = 0;
-                for (int y = 0; y < 5; y++) id |= (best[y][1] << 1 | best[y][3]) << 2 * (4 - y);
-            }
+            cand->id = id;
+            cand->nrot = nrot;
         }
-        cand->id = id;
-        cand->nrot = nrot;
     }
 }
 
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     DecodeArgs a;
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride, a.width = g.width, a.height = g.height;
-    a.ws = p.warp_size, a.cands = b.cands, a.ncands = b.ncands, a.cap_cands = b.cap_cands;
-    hipLaunchKernelGGL(decode_kernel, dim3(b.cap_cands, nframes), dim3(64), (size_t)((p.warp_size * p.warp_size + 15) & ~15), s, a);
+    a.ws = p.warp_size, a.cands = b.cands, a.cap_cands = b.cap_cands;
+    a.cand_list = b.cand_list, a.counters = b.counters, a.cap_flat = b.cap_flat, a.iM = b.iM, a.hist = b.hist, a.othr = b.othr, a.patches = b.patches;
+    const int lane_blocks = (int)((b.cap_flat + 63) / 64);
+    const int wave_blocks = (int)std::min<uint32_t>(b.cap_flat, (uint32_t)nframes * 48u);
+    hipLaunchKernelGGL(homography_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(warp_hist_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(otsu_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(cells_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
 }
 
 // MarkerDetector::warp as a stage entry point: one patch from one quad
