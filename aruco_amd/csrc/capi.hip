@@ -24,10 +24,10 @@ using namespace ah;
 enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_COUNT };
 static const char* kStageNames[STAGE_COUNT] = {"Threshold", "Rectangles", "Identify", "Subpixel", "Filtering"};
 // one event after every kernel of a batch; a ring of TSETS batches so that asynchronous steps can be averaged
-enum { K_THRESHOLD = 0, K_WALKERS, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
+enum { K_THRESHOLD = 0, K_FILTER, K_WALKERS, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "filter_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
                                             "decode_kernel", "refine_lines_kernel", "refine_pixels_kernel", "finalize_kernel", "pose_kernel"};
-static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_IDENTIFY,
+static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_IDENTIFY,
                                           STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_FILTERING};
 constexpr int TSETS = 32;
 
@@ -413,23 +413,24 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     launch_threshold(s, gray_dev, g, nframes, dp, b);
     MARK(1);
     launch_filter(s, g, nframes * dp.nthr, b);
-    launch_walkers(s, g, nframes * dp.nthr, dp, b);
     MARK(2);
-    launch_contour_quads(s, g, nframes, dp, b);
+    launch_walkers(s, g, nframes * dp.nthr, dp, b);
     MARK(3);
-    launch_frame_candidates(s, g, nframes, dp, b);
+    launch_contour_quads(s, g, nframes, dp, b);
     MARK(4);
-    launch_decode(s, gray_dev, g, nframes, dp, b);
+    launch_frame_candidates(s, g, nframes, dp, b);
     MARK(5);
-    launch_refine_lines(s, g, nframes, dp, cam, b);
+    launch_decode(s, gray_dev, g, nframes, dp, b);
     MARK(6);
+    launch_refine_lines(s, g, nframes, dp, cam, b);
+    MARK(7);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX)
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
-    MARK(7);
-    launch_finalize(s, g, nframes, dp, cam, b);
     MARK(8);
-    if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
+    launch_finalize(s, g, nframes, dp, cam, b);
     MARK(9);
+    if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
+    MARK(10);
 #undef MARK
     if (tm) h->tsets++;
     HIPCHK(h, hipGetLastError());

@@ -56,24 +56,21 @@ def _paint_quad(img, quad, table, cells, lo, ss=3):
     Hi = torch.tensor(Hinv, dtype=torch.float64, device=dev)
     ys = torch.arange(y0, y1, device=dev, dtype=torch.float64)
     xs = torch.arange(x0, x1, device=dev, dtype=torch.float64)
-    acc = torch.zeros((y1 - y0, x1 - x0), dtype=torch.float32, device=dev)
-    cov = torch.zeros_like(acc)
     tab = torch.as_tensor(table, dtype=torch.float32, device=dev)
     n = tab.shape[0]
-    for sy in range(ss):
-        for sx in range(ss):
-            # pixel (x, y) covers [x-0.5, x+0.5): sample centres inside it
-            px = xs[None, :] + ((sx + 0.5) / ss - 0.5)
-            py = ys[:, None] + ((sy + 0.5) / ss - 0.5)
-            w = Hi[2, 0] * px + Hi[2, 1] * py + Hi[2, 2]
-            u = (Hi[0, 0] * px + Hi[0, 1] * py + Hi[0, 2]) / w
-            v = (Hi[1, 0] * px + Hi[1, 1] * py + Hi[1, 2]) / w
-            inside = (u >= lo) & (u < lo + cells) & (v >= lo) & (v < lo + cells)
-            ui = torch.clamp((u - lo).floor().long(), 0, n - 1)
-            vi = torch.clamp((v - lo).floor().long(), 0, n - 1)
-            val = tab[vi, ui]
-            acc += torch.where(inside, val, torch.zeros_like(val))
-            cov += inside.float()
+    # all ss*ss sub-samples of every pixel at once: pixel (x, y) covers [x-0.5, x+0.5)
+    offs = (torch.arange(ss, device=dev, dtype=torch.float64) + 0.5) / ss - 0.5
+    px = (xs[None, :] + offs[:, None]).reshape(ss, 1, 1, x1 - x0)   # [ss_x, 1, 1, w]
+    py = (ys[None, :] + offs[:, None]).reshape(1, ss, y1 - y0, 1)   # [1, ss_y, h, 1]
+    w = Hi[2, 0] * px + Hi[2, 1] * py + Hi[2, 2]
+    u = (Hi[0, 0] * px + Hi[0, 1] * py + Hi[0, 2]) / w
+    v = (Hi[1, 0] * px + Hi[1, 1] * py + Hi[1, 2]) / w
+    inside = (u >= lo) & (u < lo + cells) & (v >= lo) & (v < lo + cells)
+    ui = torch.clamp((u - lo).floor().long(), 0, n - 1)
+    vi = torch.clamp((v - lo).floor().long(), 0, n - 1)
+    val = tab[vi, ui]
+    acc = torch.where(inside, val, torch.zeros_like(val)).sum(dim=(0, 1))
+    cov = inside.float().sum(dim=(0, 1))
     k = float(ss * ss)
     region = img[y0:y1, x0:x1]
     img[y0:y1, x0:x1] = region * (1 - cov / k) + acc / k

@@ -70,8 +70,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
-    ap.add_argument("--frames", type=int, default=256, help="distinct synthetic frames per GPU (SURVEY: up to 1024)")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step and GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="distinct synthetic frames per GPU (SURVEY.md config 2: N=1024)")
     ap.add_argument("--pose", action="store_true", help="config 3: intrinsics + per-marker solvePnP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
