@@ -127,7 +127,7 @@ static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
     hipFree(h->buf.thres), hipFree(h->buf.bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -183,6 +183,20 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
     ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
+    {
+        const char* mode = getenv("ARUCOHIP_CONTOURS");
+        b.seg_mode = (mode && std::string(mode) == "segments");   // default: walkers (faster at large batches)
+        const char* gs = getenv("ARUCOHIP_GRID");
+        int grid = gs ? atoi(gs) : 16;
+        if (grid != 1 && grid != 2 && grid != 4 && grid != 8 && grid != 16 && grid != 32) grid = 8;
+        b.grid_mask = grid - 1;
+        uint32_t hs = 1;
+        while (hs < 2u * b.cap_raw) hs <<= 1;
+        b.hash_mask = hs - 1;
+    }
+    ALLOC(b.node, P * (size_t)b.cap_raw * sizeof(uint4));
+    ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
+    ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.cdesc, (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, (size_t)b.cap_pool * sizeof(short2));
@@ -321,7 +335,7 @@ static int make_detect_params(arucohip_handle* h, int W, int H, DetectParams* dp
     dp->warp_size = p.warp_size;
     dp->min_contour = (int)(p.min_size * std::max(W, H) * 4);   // :500-501, float arithmetic
     dp->max_contour = (int)(p.max_size * std::max(W, H) * 4);
-    if (dp->max_contour > 32760) dp->max_contour = 32760;       // contour points live in LDS as short2
+    if (dp->max_contour > 16383) dp->max_contour = 16383;       // offsets inside a border are 14-bit fields
     // :433-434 Rect(Point(size)*t, Point(size)*(1-t)) with cvRound
     int x1 = (int)lrintf((float)W * p.border_dist), y1 = (int)lrintf((float)H * p.border_dist);
     int x2 = (int)lrintf((float)W * (1.0f - p.border_dist)), y2 = (int)lrintf((float)H * (1.0f - p.border_dist));
@@ -352,6 +366,7 @@ static int check_status(arucohip_handle* h, uint32_t st) {
              (st & ST_CDESC_OVERFLOW) ? " contours" : "", (st & ST_POOL_OVERFLOW) ? " points" : "",
              (st & ST_QUAD_OVERFLOW) ? " quads" : "", (st & ST_CAND_OVERFLOW) ? " candidates" : "",
              (st & ST_MARKER_OVERFLOW) ? " markers" : "");
+    if (st & ST_SEGMENT_ERROR) snprintf(msg + strlen(msg), sizeof(msg) - strlen(msg), " segment-link");
     h->err = msg;
     return ARUCOHIP_E_OVERFLOW;
 }
@@ -388,8 +403,13 @@ static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectPara
 
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
-    launch_filter(h->stream, g, nframes * dp.nthr, h->buf);
-    launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
+    if (h->buf.seg_mode) {
+        (void)hipMemsetAsync(h->buf.hash, 0xFF, (size_t)nframes * dp.nthr * (h->buf.hash_mask + 1) * sizeof(uint32_t), h->stream);
+        launch_segments(h->stream, g, nframes * dp.nthr, dp, h->buf);
+    } else {
+        launch_filter(h->stream, g, nframes * dp.nthr, h->buf);
+        launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
+    }
     launch_contour_quads(h->stream, g, nframes, dp, h->buf);
     launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
 }
@@ -412,9 +432,15 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     MARK(0);
     launch_threshold(s, gray_dev, g, nframes, dp, b);
     MARK(1);
-    launch_filter(s, g, nframes * dp.nthr, b);
-    MARK(2);
-    launch_walkers(s, g, nframes * dp.nthr, dp, b);
+    if (b.seg_mode) {
+        HIPCHK(h, hipMemsetAsync(b.hash, 0xFF, (size_t)nframes * dp.nthr * (b.hash_mask + 1) * sizeof(uint32_t), s));
+        MARK(2);
+        launch_segments(s, g, nframes * dp.nthr, dp, b);
+    } else {
+        launch_filter(s, g, nframes * dp.nthr, b);
+        MARK(2);
+        launch_walkers(s, g, nframes * dp.nthr, dp, b);
+    }
     MARK(3);
     launch_contour_quads(s, g, nframes, dp, b);
     MARK(4);

@@ -41,6 +41,7 @@ enum StatusBits {
     ST_QUAD_OVERFLOW = 8,
     ST_CAND_OVERFLOW = 16,
     ST_MARKER_OVERFLOW = 32,
+    ST_SEGMENT_ERROR = 64,
 };
 
 struct ContourDesc {
@@ -105,6 +106,10 @@ struct Buffers {
     ContourDesc* cdesc;
     short2* pool;
     uint32_t* walk_scratch; // checkpoint rings of the walker lanes
+    uint4* node;            // [P][cap_raw] waypoint records of the segment pipeline
+    unsigned long long* stamp; // [P][cap_raw] (start key, start node, offset) of the start that owns the node
+    uint32_t* hash;         // [P][hash_mask+1] node index by waypoint key
+    uint32_t hash_mask;
     Quad* quads;
     Cand* cands;
     int32_t* ncands;       // [F]
@@ -118,6 +123,7 @@ struct Buffers {
     int32_t* nmarkers;     // [F]
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;   // per plane
+    int seg_mode, grid_mask;      // contour pipeline: 0 = walkers, 1 = waypoint segments (grid spacing = grid_mask + 1)
     uint32_t cap_cdesc, cap_pool;
     int cap_quads, cap_cands, cap_markers;   // per frame
 };
@@ -127,6 +133,7 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
+void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

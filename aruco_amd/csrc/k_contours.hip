@@ -274,6 +274,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 struct QuadArgs {
     const uint32_t* bits;
     int wb;
+    int from_pool;     // segment pipeline: the points are already in the pool
     const ContourDesc* cdesc;
     short2* pool;
     Quad* quads;
@@ -296,8 +297,10 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
         const int count = cd.n;
         __syncthreads();
         if (count <= 0) continue;
-        // ---- emit the border: every lane resumes the walk at one checkpoint and records CK points
-        {
+        // ---- points: already emitted (segment pipeline) or every lane resumes the walk at one checkpoint and records CK points
+        if (a.from_pool) {
+            for (int i = lane; i < count; i += WAVE) P[i] = a.pool[cd.pool_off + i];
+        } else {
             const uint32_t* bits = a.bits + (size_t)cd.plane * a.wb * a.height;
             const int ncp = (count + CK - 1) / CK;
             const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
@@ -319,7 +322,8 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
             }
         }
         __syncthreads();
-        for (int i = lane; i < count; i += WAVE) a.pool[cd.pool_off + i] = P[i];
+        if (!a.from_pool)
+            for (int i = lane; i < count; i += WAVE) a.pool[cd.pool_off + i] = P[i];
 
         // ---- cv::approxPolyDP(closed), restated for a wavefront: every "farthest point" scan is a 64-lane argmax with
         // first-maximum tie break (lowest scan position), control flow is wave-uniform.
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
 
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     QuadArgs a;
-    a.bits = b.bits, a.wb = bits_pitch(g.width), a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
+    a.bits = b.bits, a.wb = bits_pitch(g.width), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
     hipLaunchKernelGGL(contour_quad_kernel, dim3(256 * 8), dim3(64), sh, s, a);

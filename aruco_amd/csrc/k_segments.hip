@@ -1,0 +1,324 @@
+// Parallel border extraction ("waypoint segments") — replaces the sequential scan of cv::findContours
+// (/root/reference/src/markerdetector.cpp:511) without long sequential walks.
+//
+// A border, as OpenCV follows it, is a cyclic sequence of VISITS (pixel p, direction s towards the previous pixel);
+// during a visit the follower examines, counter-clockwise from s+1, the clear neighbours up to the next set one. Every
+// CRACK (set pixel p, clear 4-neighbour in direction e) is examined in exactly one visit of exactly one border, and that
+// visit's state is a function of the 3x3 neighbourhood alone: s = first set neighbour clockwise from e.
+//
+//  1. Kernel 1 emits WAYPOINTS: the cracks on a sparse grid (W/E cracks on rows y % S == 0, N/S cracks on columns
+//     x % S == 0) plus every crack that can start a border (the 3x3 start rule). Every border that spans more than S rows
+//     or columns crosses a grid line and therefore carries waypoints every few pixels.
+//  2. segment_kernel (one lane per waypoint): follow the border from the waypoint's visit until the next waypoint crack is
+//     examined (a handful of steps). Records the next waypoint's key, the number of visits moved and the smallest
+//     start key met (W crack: pos(p); E crack: pos(p)+1 — the candidates for OpenCV's scan transition).
+//  3. link_kernel: next key -> node index through a per-plane hash table.
+//  4. cycle_kernel (one lane per start-candidate waypoint that passes the run rule): hop from node to node around the
+//     cycle, summing lengths; drop out when a smaller start key exists on the cycle or the border exceeds the size filter.
+//     The survivor of a cycle is OpenCV's start; a second lap stamps every node with its offset in the output.
+//  5. emit_kernel (one lane per stamped node): re-follow the node's few visits and write the points at their final
+//     positions. Point order, start pixel and direction equal cv::findContours(RETR_LIST, CHAIN_APPROX_NONE).
+#include "internal.h"
+
+namespace ah {
+
+// ---- shared border-following primitives (same tables as k_contours.hip)
+__device__ __forceinline__ uint32_t sg_dpos(int d) {
+    const uint32_t nib = (0xA9840126u >> (4 * d)) & 15u;
+    return ((nib >> 2) << 16) + (nib & 3u) - 65537u;
+}
+
+__device__ __forceinline__ uint32_t sg_mask(const uint32_t* __restrict__ bits, int wb, uint32_t pos) {
+    const uint32_t xm = (pos & 0xFFFFu) - 1u, y = pos >> 16;
+    const uint32_t sh = xm & 31u;
+    const uint32_t* r = bits + (y - 1u) * (uint32_t)wb + (xm >> 5);
+    const uint32_t a0 = r[0], a1 = r[1], b0 = r[wb], b1 = r[wb + 1], c0 = r[2 * wb], c1 = r[2 * wb + 1];
+    const uint32_t up = __builtin_amdgcn_alignbit(a1, a0, sh) & 7u;
+    const uint32_t mid = __builtin_amdgcn_alignbit(b1, b0, sh) & 7u;
+    const uint32_t dn = __builtin_amdgcn_alignbit(c1, c0, sh) & 7u;
+    return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
+}
+
+// first set neighbour clockwise from direction e (exclusive); mask must be non-zero
+__device__ __forceinline__ int cw_first(uint32_t m, int e) {
+    const uint32_t r = ((m | (m << 8)) >> e) & 0xFFu;   // bit t <-> direction e + t
+    return (e + (31 - __builtin_clz(r))) & 7;            // highest set bit = first one met going clockwise from e
+}
+// first set neighbour counter-clockwise from direction s (exclusive); *k = number of clear neighbours passed
+__device__ __forceinline__ int ccw_first(uint32_t m, int s, int* k) {
+    const uint32_t sh = (uint32_t)(s + 1) & 7u;
+    const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
+    *k = __builtin_ctz(rot | 0x100u);
+    return (int)((sh + (uint32_t)*k) & 7u);
+}
+
+struct SegArgs {
+    const uint32_t* bits;
+    int wb, width, height, nplanes;
+    int grid_mask;
+    const uint2* raw;           // waypoints {cand, key}
+    const uint32_t* raw_cnt;
+    uint32_t cap_raw;           // nodes per plane
+    // node records [P][cap_raw]: x = key of the next waypoint (later its node index), y = smallest start key among the
+    // cracks examined in this segment, z = visits moved | flag << 16 (flag 1: start candidate after the run rule, 2: dead)
+    uint4* node;
+    // stamp of the smallest start key that lapped over the node: key(30) << 34 | start node(20) << 14 | visits from the start(14)
+    unsigned long long* stamp;
+    uint32_t* hash;             // [P][hash_size] node index by key
+    uint32_t hash_mask;
+    ContourDesc* cdesc;
+    short2* pool;
+    uint32_t* counters;
+    uint32_t cap_cdesc, cap_pool;
+    int min_contour, max_contour;
+};
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr unsigned long long NONE64 = ~0ull;
+
+// 1-D grids: workgroups are dealt round-robin over the 8 XCDs; unpack the block id so that all workgroups of one plane
+// share an XCD (its L2 then holds that plane's bit image, node records and hash table).
+__device__ __forceinline__ bool plane_of_block(int nplanes, int chunks, int* plane, int* chunk) {
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    *chunk = rest % chunks;
+    *plane = (rest / chunks) * 8 + xcd;
+    return *plane < nplanes;
+}
+constexpr int SEG_CHUNKS = 16;   // 256-thread workgroups per plane in the per-node kernels
+constexpr int CYC_CHUNKS = 32;   // 64-thread workgroups per plane in the lap kernel
+
+__device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask) { return (key * 2654435761u >> 7) & mask; }
+
+// run rule (see filter_kernel in k_contours.hip) for a start-candidate crack
+__device__ __forceinline__ bool run_rule(const uint32_t* bits, int wb, uint32_t pos, int e) {
+    const int hole = e == 0;
+    const uint32_t zpos = pos + (hole ? 1u : 0u);            // outer: the pixel itself; hole: the clear pixel right of p
+    const int x = (int)(zpos & 0xFFFFu), y = (int)(zpos >> 16);
+    const int w = x >> 5, sh = x & 31, avail = 64 - sh;
+    const uint32_t* r = bits + (size_t)y * wb + w;
+    const uint64_t mid = ((uint64_t)r[0] | ((uint64_t)r[1] << 32)) >> sh;
+    const uint64_t up = ((uint64_t)(r - wb)[0] | ((uint64_t)(r - wb)[1] << 32)) >> sh;
+    if (!hole) {
+        int L = (~mid) ? __builtin_ctzll(~mid) : 64;
+        L = min(L, avail);
+        const int hi = min(L, avail - 1);
+        const uint64_t mm = hi >= 2 ? ((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~3ull) : 0ull;
+        return (up & mm) == 0;
+    }
+    int L = mid ? __builtin_ctzll(mid) : 64;
+    L = min(L, avail);
+    const int hi = min(L - 1, avail - 1);
+    const uint64_t mm = hi >= 1 ? ((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~1ull) : 0ull;
+    return (~up & mm) == 0;
+}
+
+// Is crack (pos, direction e) a waypoint? Grid cracks always; start-candidate cracks (3x3 rule of kernel 1) only when
+// they also pass the run rule — the segment kernel discards the other candidates kernel 1 emitted, with this same test.
+__device__ __forceinline__ bool on_grid(uint32_t pos, int e, int grid_mask) {
+    return (e & 2) ? ((pos & 0xFFFFu) & grid_mask) == 0 : ((pos >> 16) & grid_mask) == 0;   // N,S: column; W,E: row
+}
+__device__ __forceinline__ bool is_waypoint(const uint32_t* bits, int wb, uint32_t pos, int e, uint32_t m, int grid_mask, int width) {
+    if (on_grid(pos, e, grid_mask)) return true;
+    if (e == 4 && (m & 0x1Eu) == 0) return run_rule(bits, wb, pos, 4);                                               // outer start: W,NW,N,NE clear
+    if (e == 0 && ((m >> 1) & 1u) && (int)(pos & 0xFFFFu) + 1 <= width - 2) return run_rule(bits, wb, pos, 0);    // hole start: z inside, N(z) set
+    return false;
+}
+
+// Kernel S2: one lane per waypoint.
+__global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const size_t nb = (size_t)plane * a.cap_raw;
+    uint32_t* hash = a.hash + (size_t)plane * (a.hash_mask + 1);
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
+        const uint2 rec = a.raw[nb + i];
+        const uint32_t key = rec.y, pos0 = key >> 2;
+        const int e0 = (int)(key & 3u) * 2;
+        a.stamp[nb + i] = NONE64;
+        uint32_t m = sg_mask(bits, a.wb, pos0);
+        uint8_t flag = 0;
+        if (rec.x & 1u) flag = run_rule(bits, a.wb, pos0, e0) ? 1 : 0;
+        // not a node: isolated pixel (a one-point border, never kept) or a start candidate the run rule rejects off the grid
+        if (m == 0 || (!flag && !on_grid(pos0, e0, a.grid_mask))) {
+            a.node[nb + i] = make_uint4(key, NONE32, 2u << 16, NONE32);
+            continue;
+        }
+        // publish this node under its key
+        for (uint32_t slot = hash_key(key, a.hash_mask);; slot = (slot + 1) & a.hash_mask)
+            if (atomicCAS(&hash[slot], NONE32, i) == NONE32) break;
+        int s = cw_first(m, e0);
+        uint32_t pos = pos0, mn = NONE32, len = 0, next_key = NONE32;
+        int from = e0;   // cracks after direction `from` (counter-clockwise) are still to come in this visit
+        // a border that avoids the grid is confined to one S x S cell: at most 4 visits per pixel
+        const int max_steps = 4 * (a.grid_mask + 1) * (a.grid_mask + 1) + 8;
+        for (int step = 0; step <= max_steps; step++) {
+            int k;
+            const int d = ccw_first(m, s, &k);
+            // clear neighbours examined in this visit: directions s+1 .. d-1; keep those after `from`
+            int t = (from - s) & 7;          // `from` is the t-th examined direction (t >= 1), or 0 at a fresh visit
+            for (int q = t + 1; q <= k; q++) {
+                const int dir = (s + q) & 7;
+                if (dir & 1) continue;       // diagonal neighbours are not cracks
+                if (dir == 4) mn = min(mn, pos);
+                if (dir == 0) mn = min(mn, pos + 1u);
+                if (is_waypoint(bits, a.wb, pos, dir, m, a.grid_mask, a.width)) {
+                    next_key = (pos << 2) | (uint32_t)(dir >> 1);
+                    break;
+                }
+            }
+            if (next_key != NONE32) break;
+            pos += sg_dpos(d);
+            s = (d + 4) & 7;
+            from = s;
+            len++;
+            m = sg_mask(bits, a.wb, pos);
+        }
+        if (next_key == NONE32) {   // no waypoint within the bound: cannot happen for borders that cross the grid
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_SEGMENT_ERROR);
+            flag = 2, next_key = key, len = 0;
+        }
+        a.node[nb + i] = make_uint4(next_key, mn, len | ((uint32_t)flag << 16), NONE32);
+    }
+}
+
+// Kernel S3: next key -> node index
+__global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const size_t nb = (size_t)plane * a.cap_raw;
+    const uint32_t* hash = a.hash + (size_t)plane * (a.hash_mask + 1);
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
+        const uint4 nd = a.node[nb + i];
+        const uint32_t key = nd.x;
+        uint32_t found = i;   // a dead node points at itself
+        if (!((nd.z >> 16) & 2u)) {
+            found = NONE32;
+            for (uint32_t slot = hash_key(key, a.hash_mask), probes = 0; probes <= a.hash_mask; slot = (slot + 1) & a.hash_mask, probes++) {
+                const uint32_t j = hash[slot];
+                if (j == NONE32) break;
+                if (a.raw[nb + j].y == key) {
+                    found = j;
+                    break;
+                }
+            }
+            if (found == NONE32) {
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_SEGMENT_ERROR);
+                found = i;
+            }
+        }
+        a.node[nb + i].x = found;
+    }
+}
+
+// Kernel S4: one lane per start candidate: ONE lap around the cycle of nodes. Every node passed is stamped (atomicMin) with
+// (start key, start node, visits from the start): the true start has the smallest key of its cycle and completes its
+// lap, so afterwards every node of a kept border carries the true start's stamp; false starts drop out at the first
+// node whose segment holds a smaller key and can only leave larger stamps behind.
+__global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, CYC_CHUNKS, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const size_t nb = (size_t)plane * a.cap_raw;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += CYC_CHUNKS * blockDim.x) {
+        if ((a.node[nb + i].z >> 16) != 1u) continue;
+        const uint32_t key = a.raw[nb + i].y, pos0 = key >> 2;
+        const int hole = (key & 3u) == 0;
+        const uint32_t k0 = pos0 + (hole ? 1u : 0u);     // the scan transition: outer -> the pixel, hole -> clear pixel right of it
+        const unsigned long long tag = ((unsigned long long)k0 << 34) | ((unsigned long long)i << 14);
+        uint32_t total = 0, j = i;
+        bool ok = true;
+        for (uint32_t hops = 0;; hops++) {
+            const uint4 nd = a.node[nb + j];
+            if (nd.y < k0 || hops > 4u * (uint32_t)a.max_contour) {
+                ok = false;
+                break;
+            }
+            atomicMin(&a.stamp[nb + j], tag | total);
+            total += nd.z & 0xFFFFu;
+            if (total >= (uint32_t)a.max_contour) {
+                ok = false;
+                break;
+            }
+            j = nd.x;
+            if (j == i) break;
+        }
+        if (!ok || (int)total <= a.min_contour) continue;
+        const uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
+        const uint32_t off = atomicAdd(&a.counters[CNT_POOL], total);
+        if (slot >= a.cap_cdesc) {
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+            continue;
+        }
+        ContourDesc cd;
+        cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = hole, cd.n = (int)total;
+        cd.key = (k0 >> 16) * (uint32_t)a.width + (k0 & 0xFFFFu);
+        cd.pool_off = off;
+        if (off + total > a.cap_pool) {
+            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
+            cd.n = 0;
+            a.cdesc[slot] = cd;
+            continue;
+        }
+        a.cdesc[slot] = cd;
+        a.node[nb + i].w = slot;   // emit_kernel finds the descriptor through the start node
+    }
+}
+
+// Kernel S5: one lane per node of a kept border: write the points of its visits
+__global__ __launch_bounds__(256) void emit_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const size_t nb = (size_t)plane * a.cap_raw;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
+        const unsigned long long st = a.stamp[nb + i];
+        if (st == NONE64) continue;
+        const uint32_t len = a.node[nb + i].z & 0xFFFFu;
+        if (len == 0) continue;
+        const uint32_t ci = a.node[nb + (uint32_t)((st >> 14) & 0xFFFFFu)].w;   // descriptor of the stamping start, if it was kept
+        if (ci == NONE32) continue;
+        const ContourDesc cd = a.cdesc[ci];
+        const uint32_t key = a.raw[nb + i].y;
+        uint32_t pos = key >> 2;
+        uint32_t m = sg_mask(bits, a.wb, pos);
+        int s = cw_first(m, (int)(key & 3u) * 2);
+        short2* out = a.pool + cd.pool_off;
+        uint32_t idx = (uint32_t)(st & 0x3FFFu);
+        const uint32_t total = (uint32_t)cd.n;
+        for (uint32_t t = 0; t < len; t++) {
+            int k;
+            const int d = ccw_first(m, s, &k);
+            pos += sg_dpos(d);
+            s = (d + 4) & 7;
+            if (++idx >= total) idx -= total;
+            out[idx] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
+            if (t + 1 < len) m = sg_mask(bits, a.wb, pos);
+        }
+    }
+}
+
+static void fill_seg_args(SegArgs& a, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
+    a.bits = b.bits, a.wb = bits_pitch(g.width), a.width = g.width, a.height = g.height, a.nplanes = nplanes;
+    a.grid_mask = b.grid_mask;
+    a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.cap_raw = b.cap_raw;
+    a.node = b.node, a.stamp = b.stamp;
+    a.hash = b.hash, a.hash_mask = b.hash_mask;
+    a.cdesc = b.cdesc, a.pool = b.pool, a.counters = b.counters, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
+    a.min_contour = p.min_contour, a.max_contour = p.max_contour;
+}
+
+void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
+    SegArgs a;
+    fill_seg_args(a, g, nplanes, p, b);
+    const int groups = (nplanes + 7) / 8 * 8;
+    hipLaunchKernelGGL(segment_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(link_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cycle_kernel, dim3(groups * CYC_CHUNKS), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(emit_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
+}
+
+}  // namespace ah

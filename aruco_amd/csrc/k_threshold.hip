@@ -40,6 +40,8 @@ struct ThrArgs {
     uint32_t* raw_cnt;
     uint32_t* counters;
     uint32_t cap_raw;
+    int seg_mode;         // 0: raw start candidates for the walkers, 1: waypoint cracks for the segment pipeline
+    int grid_mask;        // waypoint grid spacing - 1 (spacing is a power of two)
 };
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xFFu; }
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
     constexpr int RING = 2 * R + 1;
     constexpr int NL = (R + 3) / 4;            // neighbour dwords needed on each side for the horizontal sums
     constexpr bool PACKV = RING * RING * 255 < 65536;
-    __shared__ uint32_t s_trig[LOCAL_TRIG];
+    __shared__ uint32_t s_trig[LOCAL_TRIG], s_trig2[LOCAL_TRIG];
     __shared__ uint32_t s_ntrig, s_base;
     const int lane = threadIdx.x;
     const int frame = blockIdx.z;
@@ -70,6 +72,9 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
     uint32_t insx = 0;                                                         // pixels with 1 <= x <= W-2
 #pragma unroll
     for (int j = 0; j < 4; j++) insx |= (uint32_t)((x + j >= 1) && (x + j <= W - 2)) << j;
+    uint32_t xsel = 0;                                                         // pixels on a waypoint grid column
+#pragma unroll
+    for (int j = 0; j < 4; j++) xsel |= (uint32_t)(((x + j) & a.grid_mask) == 0) << j;
     const int xc0 = min(max(x, 0), W - 1), xc1 = min(max(x + 1, 0), W - 1), xc2 = min(max(x + 2, 0), W - 1), xc3 = min(max(x + 3, 0), W - 1);
 
     auto load_row = [&](int r) -> uint32_t {
@@ -163,20 +168,46 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
                 uint32_t outer4 = self4 & ~(w4 | nw4 | n4 | ne4);
                 uint32_t hole4 = ~self4 & w4 & n4 & insx;   // row c is inside (c >= ys >= 0; c <= H-2 checked below)
                 if (c > H - 2 || c < 1) hole4 = 0;
-                uint32_t cand = out_lane ? (outer4 | (hole4 << 4)) : 0u;
-                while (cand) {
-                    const int b = __builtin_ctz(cand);
-                    cand &= cand - 1;
-                    const uint32_t e = ((uint32_t)(b >> 2) << 31) | ((uint32_t)c << 16) | (uint32_t)(x + (b & 3));
+                auto stage = [&](uint32_t lo, uint32_t hi) {
                     const uint32_t ls = atomicAdd(&s_ntrig, 1u);
                     if (ls < LOCAL_TRIG) {
-                        s_trig[ls] = e;
+                        s_trig[ls] = lo, s_trig2[ls] = hi;
                     } else {
                         const uint32_t slot = atomicAdd(&a.raw_cnt[plane * TRIG_CNT_STRIDE], 1u);
                         if (slot < a.cap_raw)
-                            a.raw[(size_t)plane * a.cap_raw + slot] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+                            a.raw[(size_t)plane * a.cap_raw + slot] = make_uint2(hi, lo);
                         else
                             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    }
+                };
+                if (!a.seg_mode) {
+                    uint32_t cand = out_lane ? (outer4 | (hole4 << 4)) : 0u;
+                    while (cand) {
+                        const int b = __builtin_ctz(cand);
+                        cand &= cand - 1;
+                        stage(((uint32_t)c << 16) | (uint32_t)(x + (b & 3)), (uint32_t)(b >> 2));
+                    }
+                } else if (out_lane) {
+                    // waypoint cracks (pixel p set, 4-neighbour clear), see k_segments.hip:
+                    //   W / E cracks on rows y % S == 0, N / S cracks on columns x % S == 0, plus every start-candidate crack.
+                    // Record: lo = (pos(p) << 2) | code (E=0,N=1,W=2,S=3), hi = 1 if the crack is a border-start candidate.
+                    const uint32_t e4 = (Emid >> 2) & 15u;
+                    const uint32_t rowsel = ((c & a.grid_mask) == 0) ? 15u : 0u;
+                    const uint32_t crW = self4 & ~w4, crN = self4 & ~n4 & xsel, crS = n4 & ~self4 & xsel;
+                    const uint32_t crEz = ~self4 & w4 & 15u;          // seen from the clear pixel z = p + 1
+                    uint32_t ev = ((crW & (rowsel | outer4))) | ((crEz & (rowsel | hole4)) << 4) | (crN << 8) | (crS << 12);
+                    (void)e4;
+                    while (ev) {
+                        const int b = __builtin_ctz(ev);
+                        ev &= ev - 1;
+                        const int j = b & 3, kind = b >> 2;
+                        const uint32_t px = (uint32_t)(x + j);
+                        uint32_t pos, code, cand = 0;
+                        if (kind == 0) pos = ((uint32_t)c << 16) | px, code = 2u, cand = (outer4 >> j) & 1u;
+                        else if (kind == 1) pos = (((uint32_t)c << 16) | px) - 1u, code = 0u, cand = (hole4 >> j) & 1u;
+                        else if (kind == 2) pos = ((uint32_t)c << 16) | px, code = 1u;
+                        else pos = ((uint32_t)(c - 1) << 16) | px, code = 3u;
+                        stage((pos << 2) | code, cand);
                     }
                 }
             }
@@ -191,9 +222,8 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
     __syncthreads();
     const uint32_t base = s_base;
     for (uint32_t i = lane; i < nl; i += 64) {
-        const uint32_t e = s_trig[i];
         if (base + i < a.cap_raw)
-            a.raw[(size_t)plane * a.cap_raw + base + i] = make_uint2(e >> 31, e & 0x7FFFFFFFu);
+            a.raw[(size_t)plane * a.cap_raw + base + i] = make_uint2(s_trig2[i], s_trig[i]);
         else
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
     }
@@ -210,6 +240,7 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.wb = bits_pitch(g.width);
     a.thres = b.thres, a.bits = b.bits, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters, a.cap_raw = b.cap_raw;
     a.idelta = 0, a.n = 1, a.n_half = 0;
+    a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
 }
 
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
