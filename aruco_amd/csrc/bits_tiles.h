@@ -1,0 +1,106 @@
+// Tiled binary image + per-lane block cache for border following (device side).
+//
+// The image cv::findContours binarises is kept as 8x8-pixel tiles, one uint64 per tile (bit (y&7)*8 + (x&7)), row-major
+// over tiles with one zero pad tile column and row: tiles_x = ceil(W/8)+1, tiles_y = ceil(H/8)+1. A border follower needs
+// the 3x3 neighbourhood of one pixel per step; instead of three scattered reads per step every lane keeps a 32x32-pixel
+// block (4x4 tiles, 128 B = eight 16-byte loads) in LDS as 32 row words and all lanes of the wave re-centre their blocks
+// together, whenever one of them gets within a pixel of its block's edge. After a reload every lane is at least 11 pixels
+// from every edge, so the loads (and their latency) are paid once per ~11 steps instead of every step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ah {
+
+__host__ __device__ inline int tiles_x(int width) { return (width + 7) / 8 + 1; }
+__host__ __device__ inline int tiles_y(int height) { return (height + 7) / 8 + 1; }
+
+// packed pixel position y << 16 | x; a step in direction d (0=E,1=NE,2=N,3=NW,4=W,5=SW,6=S,7=SE, y down) adds tb_dpos(d)
+__device__ __forceinline__ uint32_t tb_dpos(int d) {
+    const uint32_t nib = (0xA9840126u >> (4 * d)) & 15u;   // nibble d = (dy+1) << 2 | (dx+1)
+    return ((nib >> 2) << 16) + (nib & 3u) - 65537u;
+}
+
+// up = NW,N,NE  mid = W,self,E  dn = SW,S,SE (bit 0..2)  ->  E,NE,N,NW,W,SW,S,SE (bit 0..7)
+__device__ __forceinline__ uint32_t tb_assemble(uint32_t up, uint32_t mid, uint32_t dn) {
+    return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
+}
+
+// 8 pixels of row y starting at tile column tx (bits x&7)
+__device__ __forceinline__ uint32_t tb_row_byte(const uint64_t* __restrict__ tiles, int tnx, int tx, int y) {
+    return (uint32_t)(tiles[(size_t)(y >> 3) * tnx + tx] >> (8 * (y & 7))) & 0xFFu;
+}
+
+// 3x3 neighbourhood straight from the tiles (no cache): used where only a few steps are walked
+__device__ __forceinline__ uint32_t tb_mask_direct(const uint64_t* __restrict__ tiles, int tnx, uint32_t pos) {
+    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+    const int tx = (x - 1) >> 3, sh = (x - 1) & 7;
+    uint32_t rows[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int yy = y - 1 + k;
+        const uint64_t* t = tiles + (size_t)(yy >> 3) * tnx + tx;
+        const uint32_t b16 = ((uint32_t)(t[0] >> (8 * (yy & 7))) & 0xFFu) | (((uint32_t)(t[1] >> (8 * (yy & 7))) & 0xFFu) << 8);
+        rows[k] = (b16 >> sh) & 7u;
+    }
+    return tb_assemble(rows[0], rows[1], rows[2]);
+}
+
+// up to 64 pixels of row y starting at x (bit 0 = pixel x), assembled from 9 tile bytes
+__device__ __forceinline__ uint64_t tb_row64(const uint64_t* __restrict__ tiles, int tnx, int x, int y, int* avail) {
+    const int tx = x >> 3, sh = x & 7;
+    const uint64_t* t = tiles + (size_t)(y >> 3) * tnx + tx;
+    const int by = 8 * (y & 7);
+    const int ntile = min(8, tnx - tx);          // stay inside the row of tiles (the pad column is zero)
+    uint64_t v = 0;
+    for (int k = 0; k < ntile; k++) v |= (uint64_t)((uint32_t)(t[k] >> by) & 0xFFu) << (8 * k);
+    *avail = 8 * ntile - sh;
+    return v >> sh;
+}
+
+// ---- per-lane 32x32 block in LDS: rows[r * LANES + lane], r = 0..31
+constexpr int TB_ROWS = 32;
+
+struct TileBlock {
+    int bx, by;   // pixel origin of the block (multiples of 8)
+};
+
+template <int LANES>
+__device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, uint32_t* rows, int lane, TileBlock& b) {
+    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+    const int tx0 = min(max((x - 12) >> 3, 0), tnx - 4), ty0 = min(max((y - 12) >> 3, 0), tny - 4);
+    b.bx = tx0 * 8, b.by = ty0 * 8;
+    const uint64_t* p = tiles + (size_t)ty0 * tnx + tx0;
+#pragma unroll
+    for (int tr = 0; tr < 4; tr++) {
+        const uint64_t t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+        p += tnx;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {            // low / high half of the tiles: rows 4h .. 4h+3 of this tile row
+            const uint32_t a0 = (uint32_t)(t0 >> (32 * h)), a1 = (uint32_t)(t1 >> (32 * h));
+            const uint32_t a2 = (uint32_t)(t2 >> (32 * h)), a3 = (uint32_t)(t3 >> (32 * h));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // row word = byte k of a0 | byte k of a1 << 8 | byte k of a2 << 16 | byte k of a3 << 24
+                const uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0C0C0400u + (uint32_t)k * 0x0101u);   // [a0.k, a1.k, 0, 0]
+                const uint32_t hi = __builtin_amdgcn_perm(a3, a2, 0x04000C0Cu + (uint32_t)k * 0x01010000u); // [0, 0, a2.k, a3.k]
+                rows[(tr * 8 + h * 4 + k) * LANES + lane] = lo | hi;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool tb_inside(const TileBlock& b, uint32_t pos) {
+    const int lx = (int)(pos & 0xFFFFu) - b.bx, ly = (int)(pos >> 16) - b.by;
+    return lx >= 1 && lx <= 30 && ly >= 1 && ly <= 30;
+}
+
+template <int LANES>
+__device__ __forceinline__ uint32_t tb_mask(const uint32_t* rows, int lane, const TileBlock& b, uint32_t pos) {
+    const int lx = (int)(pos & 0xFFFFu) - b.bx, ly = (int)(pos >> 16) - b.by;
+    const uint32_t* r = rows + (ly - 1) * LANES + lane;
+    const int sh = lx - 1;
+    return tb_assemble((r[0] >> sh) & 7u, (r[LANES] >> sh) & 7u, (r[2 * LANES] >> sh) & 7u);
+}
+
+}  // namespace ah

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "bits_tiles.h"
 #include "internal.h"
 
 namespace ah {
@@ -125,7 +126,7 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
 
 static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
-    hipFree(h->buf.thres), hipFree(h->buf.bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -140,7 +141,7 @@ static void free_all(arucohip_handle* h) {
 int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* lim, arucohip_handle** out) {
     if (!out || !lim) return ARUCOHIP_E_INVALID;
     *out = nullptr;
-    if (lim->max_width < 8 || lim->max_height < 8 || lim->max_width > 16383 || lim->max_height > 16383 || lim->max_batch < 1 ||
+    if (lim->max_width < 32 || lim->max_height < 32 || lim->max_width > 16383 || lim->max_height > 16383 || lim->max_batch < 1 ||
         lim->max_thres_planes < 1 || lim->max_thres_planes > 16 || lim->candidates_per_frame > 512 || lim->markers_per_frame > 256)
         return ARUCOHIP_E_INVALID;
     arucohip_handle* h = new arucohip_handle();
@@ -176,9 +177,9 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_markers = lim->markers_per_frame;
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
-    const size_t bits_bytes = P * (size_t)lim->max_height * ((size_t)lim->max_width / 32 + 2) * sizeof(uint32_t) + 64;
-    ALLOC(b.bits, bits_bytes);
-    if ((e = hipMemset(b.bits, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad words must read as zero
+    const size_t bits_bytes = P * (size_t)tiles_x(lim->max_width) * tiles_y(lim->max_height) * sizeof(uint64_t) + 64;
+    ALLOC(b.tiles, bits_bytes);
+    if ((e = hipMemset(b.tiles, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad tiles must read as zero
     h->bits_bytes = bits_bytes;
     ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
     ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
@@ -374,7 +375,7 @@ static int check_status(arucohip_handle* h, uint32_t st) {
 // the pad word of every bit-image row must be zero; its position depends on the frame width
 static int ensure_bits_geometry(arucohip_handle* h, int W, int H) {
     if (h->bits_w == W && h->bits_h == H) return ARUCOHIP_OK;
-    HIPCHK(h, hipMemsetAsync(h->buf.bits, 0, h->bits_bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.tiles, 0, h->bits_bytes, h->stream));
     h->bits_w = W, h->bits_h = H;
     return ARUCOHIP_OK;
 }
@@ -490,7 +491,7 @@ static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, 
 
 static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride) {
     if (nframes < 1 || nframes > h->lim.max_batch) return fail(h, ARUCOHIP_E_INVALID, "nframes outside 1..max_batch");
-    if (W < 8 || H < 8 || (size_t)W * H > (size_t)h->lim.max_width * h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame larger than the handle was created for");
+    if (W < 32 || H < 32 || (size_t)W * H > (size_t)h->lim.max_width * h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame larger than the handle was created for");
     if (row_stride < (size_t)W) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width");
     return ARUCOHIP_OK;
 }

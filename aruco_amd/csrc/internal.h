@@ -2,7 +2,7 @@
 //
 // HBM layout per handle (F = frames in the batch, T = threshold planes per frame, P = F*T planes):
 //   thres [P][H][W] u8   thresholded image (API-visible product, MarkerDetector::getThresholdedImage)
-//   bits  [P][H][WB] u32 binary image cv::findContours works on (bit x&31 of word x>>5; 1-px frame cleared), WB = W/32 + 1 pad
+//   tiles [P][H/8+1][W/8+1] u64 binary image cv::findContours works on, 8x8-pixel tiles (1-px frame cleared, zero pad row/col)
 //   raw   [P][capR] u32x2 local border-start candidates {hole, y<<16|x} from kernel 1
 //   trig  [P][capT] u32x2 candidates that pass the run rule
 //   cdesc list           borders that passed the size filter {plane, start, hole, n, key, pool offset}
@@ -22,8 +22,6 @@ constexpr int WAVE = 64;
 constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters
 constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
-// words per row of the bit image: one zero pad word so that two-word reads never leave the row
-__host__ __device__ inline int bits_pitch(int width) { return (width + 31) / 32 + 1; }
 
 enum Counter {
     CNT_UNUSED0 = 0,
@@ -98,7 +96,7 @@ struct DetectParams {
 // device pointers + capacities handed to kernels
 struct Buffers {
     uint8_t* thres;
-    uint32_t* bits;        // [P][H][bits_pitch(W)]
+    uint64_t* tiles;       // [P][tiles_y(H)][tiles_x(W)] binary image in 8x8-pixel tiles (bits_tiles.h)
     uint2* raw;            // [P][cap_raw] local border-start candidates per plane
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule

@@ -13,6 +13,7 @@
 //   hole border : a 4-neighbour background pixel examined during the walk precedes the trigger pixel
 // or as soon as the border is longer than the size filter admits. Survivors are exactly the borders
 // detectRectangles keeps, with the same start and direction.
+#include "bits_tiles.h"
 #include "internal.h"
 
 namespace ah {
@@ -46,30 +47,26 @@ __device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
     return (sh + k) & 7;
 }
 
-__device__ __forceinline__ uint64_t load_bits64(const uint32_t* p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 32); }
-
-// Packed pixel position: y << 16 | x. A step in direction d adds DPOS(d); raster order is the integer order.
-__device__ __forceinline__ uint32_t dpos(int d) {
-    // nibble d of the table = (dy+1) << 2 | (dx+1)
-    const uint32_t nib = (0xA9840126u >> (4 * d)) & 15u;
-    return ((nib >> 2) << 16) + (nib & 3u) - 65537u;
-}
-
-// 8-neighbour occupancy byte of the pixel at packed position `pos` from the bit image: bit d = neighbour d is set.
-// Three 8-byte reads (rows y-1, y, y+1, words (x-1)>>5 and the next one), one funnel shift each.
-__device__ __forceinline__ uint32_t nbr_mask_pos(const uint32_t* __restrict__ bits, int wb, uint32_t pos) {
-    const uint32_t xm = (pos & 0xFFFFu) - 1u, y = pos >> 16;
-    const uint32_t sh = xm & 31u;
-    const uint32_t* r = bits + (y - 1u) * (uint32_t)wb + (xm >> 5);
-    const uint32_t a0 = r[0], a1 = r[1], b0 = r[wb], b1 = r[wb + 1], c0 = r[2 * wb], c1 = r[2 * wb + 1];
-    const uint32_t up = __builtin_amdgcn_alignbit(a1, a0, sh) & 7u;
-    const uint32_t mid = __builtin_amdgcn_alignbit(b1, b0, sh) & 7u;
-    const uint32_t dn = __builtin_amdgcn_alignbit(c1, c0, sh) & 7u;
-    // up = NW,N,NE  mid = W,self,E  dn = SW,S,SE (bit 0..2)  ->  E,NE,N,NW,W,SW,S,SE (bit 0..7)
-    return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
-}
-__device__ __forceinline__ uint32_t nbr_mask(const uint32_t* bits, int wb, int x, int y) {
-    return nbr_mask_pos(bits, wb, ((uint32_t)y << 16) | (uint32_t)x);
+// Run rule on the tiled image: can the crack's pixel be the raster-first pixel of its component (outer: pixel (x,y) set)
+// or of its background hole (hole: pixel (x,y) clear, left neighbour set)?
+//   outer - no set pixel 8-adjacent to the run of set pixels starting at x in the row above
+//   hole  - no clear pixel directly above the run of clear pixels starting at x
+// Runs are followed for at most 64 pixels; a longer run keeps the candidate (the walk decides).
+__device__ __forceinline__ bool run_rule_tiles(const uint64_t* __restrict__ tiles, int tnx, int x, int y, int hole) {
+    int avail, avail_up;
+    const uint64_t mid = tb_row64(tiles, tnx, x, y, &avail), up = tb_row64(tiles, tnx, x, y - 1, &avail_up);
+    if (!hole) {
+        int L = (~mid) ? __builtin_ctzll(~mid) : 64;      // run of set pixels starting at x
+        L = min(L, avail);
+        const int hi = min(L, avail - 1);                  // blockers: row above, columns x+2 .. x+L
+        const uint64_t m = hi >= 2 ? ((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~3ull) : 0ull;
+        return (up & m) == 0;
+    }
+    int L = mid ? __builtin_ctzll(mid) : 64;               // run of clear pixels starting at x
+    L = min(L, avail);
+    const int hi = min(L - 1, avail - 1);                  // row above, columns x+1 .. x+L-1 must all be set
+    const uint64_t m = hi >= 1 ? ((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~1ull) : 0ull;
+    return (~up & m) == 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -78,14 +75,15 @@ __device__ __forceinline__ uint32_t nbr_mask(const uint32_t* bits, int wb, int x
 // its run of clear pixels. Runs are followed for at most the two loaded words; longer ones keep the candidate.
 // ---------------------------------------------------------------------------------------------
 struct FilterArgs {
-    const uint32_t* bits;
+    const uint64_t* tiles;
+    int tnx, tny;
     const uint2* raw;
     const uint32_t* raw_cnt;
     uint2* trig;
     uint32_t* trig_cnt;
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;
-    int wb, height;
+    int height;
 };
 
 // Survivors go to two lists per plane (outer starts in the first half of trig[plane], hole starts in the second half)
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
     __shared__ uint32_t s_n[2], s_base[2];
     const int plane = blockIdx.y;
     const uint32_t nraw = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
-    const uint32_t* bits = a.bits + (size_t)plane * a.wb * a.height;
+    const uint64_t* tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nraw; i0 += gridDim.x * blockDim.x) {
         if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
         __syncthreads();
@@ -103,23 +101,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
         if (i < nraw) {
             const uint2 t = a.raw[(size_t)plane * a.cap_raw + i];
             const int hole = (int)(t.x & 1u), x = (int)(t.y & 0xFFFFu), y = (int)(t.y >> 16);
-            const int w = x >> 5, sh = x & 31, avail = 64 - sh;
-            const uint32_t* r = bits + (size_t)y * a.wb + w;
-            const uint64_t mid = load_bits64(r) >> sh, up = load_bits64(r - a.wb) >> sh;
-            bool keep;
-            if (!hole) {
-                int L = (~mid) ? __builtin_ctzll(~mid) : 64;      // run of set pixels starting at x
-                L = min(L, avail);
-                const int hi = min(L, avail - 1);                  // blockers: row above, columns x+2 .. x+L
-                const uint64_t m = hi >= 2 ? (((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull))) & ~3ull) : 0ull;
-                keep = (up & m) == 0;
-            } else {
-                int L = mid ? __builtin_ctzll(mid) : 64;           // run of clear pixels starting at x
-                L = min(L, avail);
-                const int hi = min(L - 1, avail - 1);              // row above, columns x+1 .. x+L-1 must all be set
-                const uint64_t m = hi >= 1 ? (((hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull))) & ~1ull) : 0ull;
-                keep = (~up & m) == 0;
-            }
+            const bool keep = run_rule_tiles(tiles, a.tnx, x, y, hole);
             if (keep) s_keep[hole][atomicAdd(&s_n[hole], 1u)] = t;
         }
         __syncthreads();
@@ -141,8 +123,9 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
 
 void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
     FilterArgs a;
-    a.bits = b.bits, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters;
-    a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig, a.wb = bits_pitch(g.width), a.height = g.height;
+    a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
+    a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters;
+    a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig, a.height = g.height;
     hipLaunchKernelGGL(filter_kernel, dim3(8, nplanes), dim3(256), 0, s, a);
 }
 
@@ -152,8 +135,8 @@ constexpr int CK = 16;   // border steps between two checkpoints
 __device__ __forceinline__ uint32_t pack_ck(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)s << 28); }
 
 struct WalkArgs {
-    const uint32_t* bits;
-    int wb, nplanes;
+    const uint64_t* tiles;
+    int tnx, tny, nplanes;
     const uint2* trig;
     const uint32_t* trig_cnt;
     ContourDesc* cdesc;
@@ -170,49 +153,60 @@ struct WalkArgs {
 // unpacked such that all workgroups of one plane share an XCD and its L2 keeps that plane's 1-bit image (W*H/8 bytes).
 // The first half of a plane's workgroups follows outer candidates, the second half hole candidates.
 template <bool HOLE>
-__device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chunk, int nchunks) {
+__device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chunk, int nchunks, uint32_t* rows) {
     const uint32_t half = a.cap_trig / 2;
     const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
-    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     const uint2* list = a.trig + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
+    const int lane = threadIdx.x;
     uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
     const uint32_t nmax = (uint32_t)a.max_contour;
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < ntrig; i += nchunks * blockDim.x) {
-        const uint32_t tkey = list[i].y;              // y << 16 | x of the scan transition
+    for (uint32_t i0 = chunk * blockDim.x; i0 < ntrig; i0 += nchunks * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool live = i < ntrig;
+        const uint32_t tkey = live ? list[i].y : 0x00010001u;   // y << 16 | x of the scan transition
         const uint32_t pos0 = tkey - (HOLE ? 1u : 0u);
-        uint32_t m = nbr_mask_pos(bits, a.wb, pos0);
-        int s = first_dir(m, HOLE ? 0 : 4);
-        if (s < 0) continue;  // isolated pixel: 1 point, never passes the size filter
-        const uint32_t pos1 = pos0 + dpos(s);
+        TileBlock blk;
+        tb_load<64>(tiles, a.tnx, a.tny, pos0, rows, lane, blk);
+        uint32_t m = live ? tb_mask<64>(rows, lane, blk, pos0) : 0u;
+        int s = live ? first_dir(m, HOLE ? 0 : 4) : -1;
+        if (s < 0) live = false;  // isolated pixel: 1 point, never passes the size filter
+        const uint32_t pos1 = pos0 + tb_dpos(s & 7);
         uint32_t pos = pos0, n = 0;
-        bool ok = true;
-        for (;;) {
-            if ((n & (CK - 1)) == 0) ck[n / CK] = (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28);
-            // first set neighbour counter-clockwise after the direction of the previous pixel
-            const uint32_t sh = (uint32_t)(s + 1) & 7u;
-            const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
-            const int k = __builtin_ctz(rot | 0x100u);
-            const int d = (int)((sh + (uint32_t)k) & 7u);
-            bool bad;
-            if (HOLE) {
-                // smallest background 4-neighbour examined from this pixel (N < W < E < S in raster order)
-                uint32_t ex = ((1u << k) - 1u) << sh;
-                ex |= ex >> 8;
-                const uint32_t small = (ex & 4u) ? pos - 65536u : (ex & 16u) ? pos - 1u : (ex & 1u) ? pos + 1u : (ex & 64u) ? pos + 65536u : 0xFFFFFFFFu;
-                bad = small < tkey;
-            } else {
-                bad = pos < pos0;
+        bool ok = false;
+        // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
+        while (__any(live)) {
+            if (live) {
+                if ((n & (CK - 1)) == 0) ck[n / CK] = (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28);
+                // first set neighbour counter-clockwise after the direction of the previous pixel
+                const uint32_t sh = (uint32_t)(s + 1) & 7u;
+                const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
+                const int k = __builtin_ctz(rot | 0x100u);
+                const int d = (int)((sh + (uint32_t)k) & 7u);
+                bool bad;
+                if (HOLE) {
+                    // smallest background 4-neighbour examined from this pixel (N < W < E < S in raster order)
+                    uint32_t ex = ((1u << k) - 1u) << sh;
+                    ex |= ex >> 8;
+                    const uint32_t small = (ex & 4u) ? pos - 65536u : (ex & 16u) ? pos - 1u : (ex & 1u) ? pos + 1u : (ex & 64u) ? pos + 65536u : 0xFFFFFFFFu;
+                    bad = small < tkey;
+                } else {
+                    bad = pos < pos0;
+                }
+                ++n;
+                const uint32_t npos = pos + tb_dpos(d);
+                if (bad | (n >= nmax)) {
+                    live = false;
+                } else if (npos == pos0 && pos == pos1) {
+                    live = false, ok = true;
+                } else {
+                    pos = npos;
+                    s = (d + 4) & 7;
+                }
             }
-            ++n;
-            if (bad | (n >= nmax)) {
-                ok = false;
-                break;
-            }
-            const uint32_t npos = pos + dpos(d);
-            if (npos == pos0 && pos == pos1) break;
-            pos = npos;
-            s = (d + 4) & 7;
-            m = nbr_mask_pos(bits, a.wb, pos);
+            // re-centre every lane's block as soon as one live lane reaches its block's edge (wave-uniform branch)
+            if (__any(live && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            if (live) m = tb_mask<64>(rows, lane, blk, pos);
         }
         if (!ok || (int)n <= a.min_contour) continue;
         const uint32_t ncp = (n + CK - 1) / CK;
@@ -242,15 +236,16 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
     if (plane >= a.nplanes) return;
+    __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
     if (chunk < WALK_BLOCKS / 2)
-        walk_list<false>(a, plane, chunk, WALK_BLOCKS / 2);
+        walk_list<false>(a, plane, chunk, WALK_BLOCKS / 2, rows);
     else
-        walk_list<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2);
+        walk_list<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2, rows);
 }
 
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
     WalkArgs a;
-    a.bits = b.bits, a.wb = bits_pitch(g.width), a.nplanes = nplanes;
+    a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.nplanes = nplanes;
     a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
@@ -272,8 +267,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 struct QuadArgs {
-    const uint32_t* bits;
-    int wb;
+    const uint64_t* tiles;
+    int tnx, tny;
     int from_pool;     // segment pipeline: the points are already in the pool
     const ContourDesc* cdesc;
     short2* pool;
@@ -301,23 +296,23 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
         if (a.from_pool) {
             for (int i = lane; i < count; i += WAVE) P[i] = a.pool[cd.pool_off + i];
         } else {
-            const uint32_t* bits = a.bits + (size_t)cd.plane * a.wb * a.height;
+            const uint64_t* tiles = a.tiles + (size_t)cd.plane * a.tnx * a.tny;
             const int ncp = (count + CK - 1) / CK;
             const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
             for (int k = lane; k < ncp; k += WAVE) {
                 const uint32_t c = ckp[k];
                 uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
                 int s = (int)(c >> 28);
-                uint32_t m = nbr_mask_pos(bits, a.wb, pos);
+                uint32_t m = tb_mask_direct(tiles, a.tnx, pos);
                 const int n0 = k * CK, n1 = min(n0 + CK, count);
                 for (int n = n0; n < n1; n++) {
                     const uint32_t sh = (uint32_t)(s + 1) & 7u;
                     const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
                     const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
                     P[n] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
-                    pos += dpos(d);
+                    pos += tb_dpos(d);
                     s = (d + 4) & 7;
-                    if (n + 1 < n1) m = nbr_mask_pos(bits, a.wb, pos);
+                    if (n + 1 < n1) m = tb_mask_direct(tiles, a.tnx, pos);
                 }
             }
         }
@@ -483,7 +478,7 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
 
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     QuadArgs a;
-    a.bits = b.bits, a.wb = bits_pitch(g.width), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
+    a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
     hipLaunchKernelGGL(contour_quad_kernel, dim3(256 * 8), dim3(64), sh, s, a);

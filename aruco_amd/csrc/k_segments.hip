@@ -18,26 +18,10 @@
 //     The survivor of a cycle is OpenCV's start; a second lap stamps every node with its offset in the output.
 //  5. emit_kernel (one lane per stamped node): re-follow the node's few visits and write the points at their final
 //     positions. Point order, start pixel and direction equal cv::findContours(RETR_LIST, CHAIN_APPROX_NONE).
+#include "bits_tiles.h"
 #include "internal.h"
 
 namespace ah {
-
-// ---- shared border-following primitives (same tables as k_contours.hip)
-__device__ __forceinline__ uint32_t sg_dpos(int d) {
-    const uint32_t nib = (0xA9840126u >> (4 * d)) & 15u;
-    return ((nib >> 2) << 16) + (nib & 3u) - 65537u;
-}
-
-__device__ __forceinline__ uint32_t sg_mask(const uint32_t* __restrict__ bits, int wb, uint32_t pos) {
-    const uint32_t xm = (pos & 0xFFFFu) - 1u, y = pos >> 16;
-    const uint32_t sh = xm & 31u;
-    const uint32_t* r = bits + (y - 1u) * (uint32_t)wb + (xm >> 5);
-    const uint32_t a0 = r[0], a1 = r[1], b0 = r[wb], b1 = r[wb + 1], c0 = r[2 * wb], c1 = r[2 * wb + 1];
-    const uint32_t up = __builtin_amdgcn_alignbit(a1, a0, sh) & 7u;
-    const uint32_t mid = __builtin_amdgcn_alignbit(b1, b0, sh) & 7u;
-    const uint32_t dn = __builtin_amdgcn_alignbit(c1, c0, sh) & 7u;
-    return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
-}
 
 // first set neighbour clockwise from direction e (exclusive); mask must be non-zero
 __device__ __forceinline__ int cw_first(uint32_t m, int e) {
@@ -53,8 +37,8 @@ __device__ __forceinline__ int ccw_first(uint32_t m, int s, int* k) {
 }
 
 struct SegArgs {
-    const uint32_t* bits;
-    int wb, width, height, nplanes;
+    const uint64_t* tiles;
+    int tnx, tny, width, height, nplanes;
     int grid_mask;
     const uint2* raw;           // waypoints {cand, key}
     const uint32_t* raw_cnt;
@@ -89,15 +73,13 @@ constexpr int CYC_CHUNKS = 32;   // 64-thread workgroups per plane in the lap ke
 
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask) { return (key * 2654435761u >> 7) & mask; }
 
-// run rule (see filter_kernel in k_contours.hip) for a start-candidate crack
-__device__ __forceinline__ bool run_rule(const uint32_t* bits, int wb, uint32_t pos, int e) {
+// run rule for a start-candidate crack (same test as filter_kernel in k_contours.hip)
+__device__ __forceinline__ bool run_rule(const uint64_t* __restrict__ tiles, int tnx, uint32_t pos, int e) {
     const int hole = e == 0;
     const uint32_t zpos = pos + (hole ? 1u : 0u);            // outer: the pixel itself; hole: the clear pixel right of p
     const int x = (int)(zpos & 0xFFFFu), y = (int)(zpos >> 16);
-    const int w = x >> 5, sh = x & 31, avail = 64 - sh;
-    const uint32_t* r = bits + (size_t)y * wb + w;
-    const uint64_t mid = ((uint64_t)r[0] | ((uint64_t)r[1] << 32)) >> sh;
-    const uint64_t up = ((uint64_t)(r - wb)[0] | ((uint64_t)(r - wb)[1] << 32)) >> sh;
+    int avail, avail_up;
+    const uint64_t mid = tb_row64(tiles, tnx, x, y, &avail), up = tb_row64(tiles, tnx, x, y - 1, &avail_up);
     if (!hole) {
         int L = (~mid) ? __builtin_ctzll(~mid) : 64;
         L = min(L, avail);
@@ -117,64 +99,82 @@ __device__ __forceinline__ bool run_rule(const uint32_t* bits, int wb, uint32_t 
 __device__ __forceinline__ bool on_grid(uint32_t pos, int e, int grid_mask) {
     return (e & 2) ? ((pos & 0xFFFFu) & grid_mask) == 0 : ((pos >> 16) & grid_mask) == 0;   // N,S: column; W,E: row
 }
-__device__ __forceinline__ bool is_waypoint(const uint32_t* bits, int wb, uint32_t pos, int e, uint32_t m, int grid_mask, int width) {
+__device__ __forceinline__ bool is_waypoint(const uint64_t* tiles, int tnx, uint32_t pos, int e, uint32_t m, int grid_mask, int width) {
     if (on_grid(pos, e, grid_mask)) return true;
-    if (e == 4 && (m & 0x1Eu) == 0) return run_rule(bits, wb, pos, 4);                                               // outer start: W,NW,N,NE clear
-    if (e == 0 && ((m >> 1) & 1u) && (int)(pos & 0xFFFFu) + 1 <= width - 2) return run_rule(bits, wb, pos, 0);    // hole start: z inside, N(z) set
+    if (e == 4 && (m & 0x1Eu) == 0) return run_rule(tiles, tnx, pos, 4);                                               // outer start: W,NW,N,NE clear
+    if (e == 0 && ((m >> 1) & 1u) && (int)(pos & 0xFFFFu) + 1 <= width - 2) return run_rule(tiles, tnx, pos, 0);    // hole start: z inside, N(z) set
     return false;
 }
 
-// Kernel S2: one lane per waypoint.
+// Kernel S2: one lane per waypoint; the lanes of a wave step together and re-centre their 32x32 blocks together.
 __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
+    __shared__ uint32_t rows[TB_ROWS * 256];
     int plane, chunk;
     if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
-    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     const size_t nb = (size_t)plane * a.cap_raw;
     uint32_t* hash = a.hash + (size_t)plane * (a.hash_mask + 1);
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
-        const uint2 rec = a.raw[nb + i];
+    const int tid = threadIdx.x;
+    // a border that avoids the grid is confined to one S x S cell: at most 4 visits per pixel
+    const int max_steps = 4 * (a.grid_mask + 1) * (a.grid_mask + 1) + 8;
+    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += SEG_CHUNKS * blockDim.x) {
+        const uint32_t i = i0 + tid;
+        bool live = i < n;
+        const uint2 rec = live ? a.raw[nb + i] : make_uint2(0u, (0x00010001u << 2) | 2u);
         const uint32_t key = rec.y, pos0 = key >> 2;
         const int e0 = (int)(key & 3u) * 2;
-        a.stamp[nb + i] = NONE64;
-        uint32_t m = sg_mask(bits, a.wb, pos0);
+        TileBlock blk;
+        tb_load<256>(tiles, a.tnx, a.tny, pos0, rows, tid, blk);
+        uint32_t m = tb_mask<256>(rows, tid, blk, pos0);
         uint8_t flag = 0;
-        if (rec.x & 1u) flag = run_rule(bits, a.wb, pos0, e0) ? 1 : 0;
-        // not a node: isolated pixel (a one-point border, never kept) or a start candidate the run rule rejects off the grid
-        if (m == 0 || (!flag && !on_grid(pos0, e0, a.grid_mask))) {
-            a.node[nb + i] = make_uint4(key, NONE32, 2u << 16, NONE32);
-            continue;
+        if (live) {
+            a.stamp[nb + i] = NONE64;
+            if (rec.x & 1u) flag = run_rule(tiles, a.tnx, pos0, e0) ? 1 : 0;
+            // not a node: isolated pixel (a one-point border, never kept) or a start candidate the run rule rejects off the grid
+            if (m == 0 || (!flag && !on_grid(pos0, e0, a.grid_mask))) {
+                a.node[nb + i] = make_uint4(key, NONE32, 2u << 16, NONE32);
+                live = false;
+            } else {
+                // publish this node under its key
+                for (uint32_t slot = hash_key(key, a.hash_mask);; slot = (slot + 1) & a.hash_mask)
+                    if (atomicCAS(&hash[slot], NONE32, i) == NONE32) break;
+            }
         }
-        // publish this node under its key
-        for (uint32_t slot = hash_key(key, a.hash_mask);; slot = (slot + 1) & a.hash_mask)
-            if (atomicCAS(&hash[slot], NONE32, i) == NONE32) break;
-        int s = cw_first(m, e0);
+        const bool is_node = live;
+        int s = live ? cw_first(m, e0) : 0;
         uint32_t pos = pos0, mn = NONE32, len = 0, next_key = NONE32;
         int from = e0;   // cracks after direction `from` (counter-clockwise) are still to come in this visit
-        // a border that avoids the grid is confined to one S x S cell: at most 4 visits per pixel
-        const int max_steps = 4 * (a.grid_mask + 1) * (a.grid_mask + 1) + 8;
-        for (int step = 0; step <= max_steps; step++) {
-            int k;
-            const int d = ccw_first(m, s, &k);
-            // clear neighbours examined in this visit: directions s+1 .. d-1; keep those after `from`
-            int t = (from - s) & 7;          // `from` is the t-th examined direction (t >= 1), or 0 at a fresh visit
-            for (int q = t + 1; q <= k; q++) {
-                const int dir = (s + q) & 7;
-                if (dir & 1) continue;       // diagonal neighbours are not cracks
-                if (dir == 4) mn = min(mn, pos);
-                if (dir == 0) mn = min(mn, pos + 1u);
-                if (is_waypoint(bits, a.wb, pos, dir, m, a.grid_mask, a.width)) {
-                    next_key = (pos << 2) | (uint32_t)(dir >> 1);
-                    break;
+        int step = 0;
+        while (__any(live)) {
+            if (live) {
+                int k;
+                const int d = ccw_first(m, s, &k);
+                // clear neighbours examined in this visit: directions s+1 .. d-1; keep those after `from`
+                const int t = (from - s) & 7;   // `from` is the t-th examined direction (t >= 1), or 0 at a fresh visit
+                for (int q = t + 1; q <= k; q++) {
+                    const int dir = (s + q) & 7;
+                    if (dir & 1) continue;       // diagonal neighbours are not cracks
+                    if (dir == 4) mn = min(mn, pos);
+                    if (dir == 0) mn = min(mn, pos + 1u);
+                    if (is_waypoint(tiles, a.tnx, pos, dir, m, a.grid_mask, a.width)) {
+                        next_key = (pos << 2) | (uint32_t)(dir >> 1);
+                        break;
+                    }
+                }
+                if (next_key != NONE32 || ++step > max_steps) {
+                    live = false;
+                } else {
+                    pos += tb_dpos(d);
+                    s = (d + 4) & 7;
+                    from = s;
+                    len++;
                 }
             }
-            if (next_key != NONE32) break;
-            pos += sg_dpos(d);
-            s = (d + 4) & 7;
-            from = s;
-            len++;
-            m = sg_mask(bits, a.wb, pos);
+            if (__any(live && !tb_inside(blk, pos))) tb_load<256>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
+            if (live) m = tb_mask<256>(rows, tid, blk, pos);
         }
+        if (!is_node) continue;
         if (next_key == NONE32) {   // no waypoint within the bound: cannot happen for borders that cross the grid
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_SEGMENT_ERROR);
             flag = 2, next_key = key, len = 0;
@@ -269,40 +269,57 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
 
 // Kernel S5: one lane per node of a kept border: write the points of its visits
 __global__ __launch_bounds__(256) void emit_kernel(SegArgs a) {
+    __shared__ uint32_t rows[TB_ROWS * 256];
     int plane, chunk;
     if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
-    const uint32_t* __restrict__ bits = a.bits + (size_t)plane * a.wb * a.height;
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     const size_t nb = (size_t)plane * a.cap_raw;
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
-        const unsigned long long st = a.stamp[nb + i];
-        if (st == NONE64) continue;
-        const uint32_t len = a.node[nb + i].z & 0xFFFFu;
-        if (len == 0) continue;
-        const uint32_t ci = a.node[nb + (uint32_t)((st >> 14) & 0xFFFFFu)].w;   // descriptor of the stamping start, if it was kept
-        if (ci == NONE32) continue;
-        const ContourDesc cd = a.cdesc[ci];
-        const uint32_t key = a.raw[nb + i].y;
+    const int tid = threadIdx.x;
+    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += SEG_CHUNKS * blockDim.x) {
+        const uint32_t i = i0 + tid;
+        bool live = i < n;
+        unsigned long long st = NONE64;
+        uint32_t len = 0, ci = NONE32;
+        if (live) {
+            st = a.stamp[nb + i];
+            len = a.node[nb + i].z & 0xFFFFu;
+            if (st != NONE64 && len) ci = a.node[nb + (uint32_t)((st >> 14) & 0xFFFFFu)].w;   // descriptor of the stamping start, if kept
+        }
+        live = live && ci != NONE32;
+        if (!__any(live)) continue;
+        const uint32_t key = live ? a.raw[nb + i].y : ((0x00010001u << 2) | 2u);
         uint32_t pos = key >> 2;
-        uint32_t m = sg_mask(bits, a.wb, pos);
-        int s = cw_first(m, (int)(key & 3u) * 2);
-        short2* out = a.pool + cd.pool_off;
-        uint32_t idx = (uint32_t)(st & 0x3FFFu);
-        const uint32_t total = (uint32_t)cd.n;
-        for (uint32_t t = 0; t < len; t++) {
-            int k;
-            const int d = ccw_first(m, s, &k);
-            pos += sg_dpos(d);
-            s = (d + 4) & 7;
-            if (++idx >= total) idx -= total;
-            out[idx] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
-            if (t + 1 < len) m = sg_mask(bits, a.wb, pos);
+        TileBlock blk;
+        tb_load<256>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
+        uint32_t m = tb_mask<256>(rows, tid, blk, pos);
+        int s = live ? cw_first(m, (int)(key & 3u) * 2) : 0;
+        short2* out = a.pool;
+        uint32_t idx = (uint32_t)(st & 0x3FFFu), total = 1;
+        if (live) {
+            const ContourDesc cd = a.cdesc[ci];
+            out = a.pool + cd.pool_off;
+            total = (uint32_t)cd.n;
+        }
+        uint32_t t = 0;
+        while (__any(live)) {
+            if (live) {
+                int k;
+                const int d = ccw_first(m, s, &k);
+                pos += tb_dpos(d);
+                s = (d + 4) & 7;
+                if (++idx >= total) idx -= total;
+                out[idx] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
+                if (++t >= len) live = false;
+            }
+            if (__any(live && !tb_inside(blk, pos))) tb_load<256>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
+            if (live) m = tb_mask<256>(rows, tid, blk, pos);
         }
     }
 }
 
 static void fill_seg_args(SegArgs& a, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
-    a.bits = b.bits, a.wb = bits_pitch(g.width), a.width = g.width, a.height = g.height, a.nplanes = nplanes;
+    a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.width = g.width, a.height = g.height, a.nplanes = nplanes;
     a.grid_mask = b.grid_mask;
     a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.cap_raw = b.cap_raw;
     a.node = b.node, a.stamp = b.stamp;

@@ -10,11 +10,12 @@
 //   * the running vertical sums V (added row in, row out),
 // so every gray byte is read from HBM/L2 once (plus the halo overlap), there is no LDS tile and no re-read.
 // mean = round(S / b^2) is never formed: src - mean <= -C  <=>  (src + C) * b^2 <= S + b^2/2 (exact in integers).
-// Per output row the wave stores 224 threshold bytes (one dword per lane), seven 32-bit words of the binary image
-// (1-px frame cleared, the image cv::findContours binarises) and stages the local border-start candidates
+// Per output row the wave stores 224 threshold bytes (one dword per lane); every 8 rows it stores 28 tiles (8x8 px, one
+// uint64 each) of the binary image (1-px frame cleared, the image cv::findContours binarises) and stages the local border-start candidates
 //   outer: pixel set,  W, NW, N, NE clear         hole: pixel clear, W and N set
 // in LDS; one atomic per flush reserves space in the plane's raw candidate list. k_contours.hip filters (run rule)
 // and verifies them. HBM traffic per frame: read W*H, write W*H + W*H/8 (+ sparse lists).
+#include "bits_tiles.h"
 #include "internal.h"
 
 namespace ah {
@@ -33,9 +34,9 @@ struct ThrArgs {
     int nthr, t;          // planes per frame, plane handled by this launch
     int idelta;           // ADPT: floor(C); FIXED: floor(threshold)
     int n, n_half;        // b*b and b*b/2
-    int wb;               // words per row of the bit image
+    int tnx, tny;         // tiles per row / column of the tiled binary image
     uint8_t* thres;
-    uint32_t* bits;
+    uint64_t* tiles;
     uint2* raw;           // raw candidate list of the plane
     uint32_t* raw_cnt;
     uint32_t* counters;
@@ -61,14 +62,15 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
     const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
     const int plane = frame * a.nthr + a.t;
     uint8_t* tdst = a.thres + (size_t)plane * W * H;
-    uint32_t* bdst = a.bits + (size_t)plane * a.wb * H;
+    uint64_t* bdst = a.tiles + (size_t)plane * a.tnx * a.tny;
+    uint64_t tile_acc = 0;                                                     // 8 rows x 8 px of this even lane's tile
     if (lane == 0) s_ntrig = 0;
     __syncthreads();
 
     const bool whole = x >= 0 && x + 3 < W;                                   // all 4 pixels inside the image
     const bool aligned = ((a.row_stride | (size_t)src) & 3) == 0;             // dword loads allowed
     const bool out_lane = lane >= 4 && lane < 60 && x < W;
-    const bool word_lane = (lane & 7) == 4 && lane < 60 && x < W;
+    const bool tile_lane = (lane & 1) == 0 && lane >= 4 && lane < 60 && x < W;   // x is a multiple of 8 on even lanes
     uint32_t insx = 0;                                                         // pixels with 1 <= x <= W-2
 #pragma unroll
     for (int j = 0; j < 4; j++) insx |= (uint32_t)((x + j >= 1) && (x + j <= W - 2)) << j;
@@ -158,11 +160,13 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
                         for (int j = 0; j < 4 && x + j < W; j++) tp[j] = (uint8_t)(t4 >> (8 * j));
                     }
                 }
-                // 32-px words: lanes 4,12,..,52 collect the nibbles of 8 lanes
-                uint32_t wv = B | (__shfl_down(B, 1, 64) << 4);
-                wv |= __shfl_down(wv, 2, 64) << 8;
-                wv |= __shfl_down(wv, 4, 64) << 16;
-                if (word_lane) bdst[(size_t)c * a.wb + (x >> 5)] = wv;
+                // 8x8 tiles: an even lane and its right neighbour hold the 8 pixels of one tile row; a tile is stored
+                // every 8 rows (segments start on multiples of 8)
+                tile_acc |= (unsigned long long)(B | (__shfl_down(B, 1, 64) << 4)) << (8 * (c & 7));
+                if ((c & 7) == 7 || c == ye - 1) {
+                    if (tile_lane) bdst[(size_t)(c >> 3) * a.tnx + (x >> 3)] = tile_acc;
+                    tile_acc = 0;
+                }
                 // border-start candidates of row c (rows c-1 and c)
                 const uint32_t self4 = B, w4 = Emid & 15u, nw4 = Eup & 15u, n4 = (Eup >> 1) & 15u, ne4 = (Eup >> 2) & 15u;
                 uint32_t outer4 = self4 & ~(w4 | nw4 | n4 | ne4);
@@ -237,8 +241,8 @@ static void launch_adpt(hipStream_t s, const ThrArgs& a, dim3 grid) {
 static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const Buffers& b, int nthr, int t) {
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
     a.width = g.width, a.height = g.height, a.nthr = nthr, a.t = t;
-    a.wb = bits_pitch(g.width);
-    a.thres = b.thres, a.bits = b.bits, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters, a.cap_raw = b.cap_raw;
+    a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
+    a.thres = b.thres, a.tiles = b.tiles, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters, a.cap_raw = b.cap_raw;
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
 }
