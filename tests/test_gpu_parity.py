@@ -267,3 +267,65 @@ def test_error_codes(env, handle):
     with pytest.raises(capi.ArucoHipError) as e:
         handle.board_detect(handle.detect(g), [], np.zeros((0, 4, 3)), 0, None, None, 1.0)
     assert e.value.code == capi.E_BOARD_CONFIG
+
+
+def test_multi_threshold_range(env):
+    """setThresholdParamRange (markerdetector.cpp:322-333): 2r+1 threshold planes per frame, candidates joined in plane
+    order — exact vs the oracle (row f2 of SURVEY §8f)."""
+    capi, orc = env["capi"], env["orc"]
+    for rng_ in (1, 2):
+        p = capi.default_params()
+        p.thres_param1_range = rng_
+        h = capi.Handle(640, 480, max_batch=2, params=p)
+        try:
+            for name in ("single", "board"):
+                g, doc = load_case(name)
+                intr = doc["intrinsics"]
+                o = orc.Oracle(thres_range=rng_)
+                ref = o.detect(g, K=intr["K"], dist=intr["dist"], marker_size=0.05)
+                got = h.detect(g, K=intr["K"], dist=intr["dist"], marker_size=0.05)
+                _compare_markers(got, ref, pose=True)
+                q, ids, nrot = h.debug_candidates(0)
+                refc = o.candidates()
+                assert len(q) == len(refc)
+                for i, r in enumerate(refc):
+                    assert np.array_equal(q[i], r["quad0"]) and ids[i] == r["id"]
+                assert np.array_equal(h.thresholded(0, g.shape), o.thresholded())   # the middle plane
+        finally:
+            h.close()
+
+
+def test_4k_board_frames(env):
+    """Config 4 of BASELINE.json: the 6x4 board of testdata/board/board_pix.yml rendered at 3840x2160 through random
+    poses; MarkerDetector + BoardDetector on device vs the oracle."""
+    capi, orc, synth = env["capi"], env["orc"], env["synth"]
+    _, doc = load_case("board")
+    bc = doc["board_conf"]
+    W, H = 3840, 2160
+    sx, sy = W / 640.0, H / 480.0                      # CameraParameters::resize rule (cameraparameters.cpp:173-178)
+    K0 = np.array(doc["intrinsics"]["K"], np.float32).reshape(3, 3)
+    K = K0.copy()
+    K[0, 0] *= np.float32(sx); K[0, 2] *= np.float32(sx); K[1, 1] *= np.float32(sy); K[1, 2] *= np.float32(sy)
+    dist = [0.0, 0.0, 0.0, 0.0, 0.0]
+    rng = np.random.RandomState(9)
+    h = capi.Handle(W, H, max_batch=2)
+    try:
+        frames = []
+        for f in range(2):
+            rvec = np.array([np.pi, 0, 0]) + rng.uniform(-0.2, 0.2, 3)
+            tvec = np.array([rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(0.52, 0.60)])
+            fr, quads = synth.render_board(bc["ids"], bc["obj"], K.astype(float), rvec, tvec, W, H, rng, device="cuda",
+                                           unit=0.039 / 100.0)
+            frames.append(fr.cpu().numpy())
+        got = h.detect_batch_host(np.stack(frames))
+        o = orc.Oracle()
+        for f in range(2):
+            ref = o.detect(frames[f])
+            assert len(ref) >= 20
+            _compare_markers(got[f], ref)
+            b = h.board_detect(got[f], bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039)
+            ob = orc.board_detect(ref, bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039)
+            assert b["has_pose"] == 1 and abs(b["prob"] - ob["prob"]) < 1e-6
+            assert rel_err(b["rvec"], ob["rvec"]) < POSE_REL_TOL and rel_err(b["tvec"], ob["tvec"]) < POSE_REL_TOL
+    finally:
+        h.close()
