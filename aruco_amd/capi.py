@@ -63,7 +63,7 @@ SYMBOLS = [
     "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
     "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
-    "arucohip_debug_counters",
+    "arucohip_debug_counters", "arucohip_board_detect_batch",
 ]
 
 _lib = None
@@ -118,6 +118,7 @@ def load():
     L.arucohip_kernel_times.argtypes = [vp, vp, i]
     L.arucohip_kernel_name.argtypes = [i]
     L.arucohip_debug_counters.argtypes = [vp, vp]
+    L.arucohip_board_detect_batch.argtypes = [vp, i, vp, vp, i, i, vp, vp, i, f, f, i, vp, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -316,3 +317,16 @@ class Handle:
         c = np.zeros(8, np.uint32)
         self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
         return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}
+
+    def board_detect_batch(self, nframes, ids, obj, info_type, K=None, dist=None, marker_size=-1.0, repj_err_thres=-1.0, y_perp=False):
+        """BoardDetector::detect on the device-resident markers of the last detect_batch call, all frames at once."""
+        ida = np.ascontiguousarray(ids, dtype=np.int32)
+        oa = _f32(obj)
+        Ka, da = _f32(K), _f32(dist)
+        out = (BoardOut * nframes)()
+        prob = np.zeros(nframes, np.float32)
+        self._chk(self.L.arucohip_board_detect_batch(self.h, nframes, _ptr(ida), _ptr(oa), len(ida), info_type, _ptr(Ka), _ptr(da),
+                                                     0 if da is None else da.size, float(marker_size), float(repj_err_thres),
+                                                     int(bool(y_perp)), out, _ptr(prob)))
+        return [{"n_markers": out[f].n_markers, "has_pose": out[f].has_pose, "rvec": np.array(out[f].rvec), "tvec": np.array(out[f].tvec),
+                 "prob": float(prob[f])} for f in range(nframes)]

@@ -53,6 +53,7 @@ struct arucohip_handle {
     double* d_small_d = nullptr;      // 64 doubles
     int* d_small_i = nullptr;
     uint8_t* d_patch = nullptr;       // MAX_WARP^2
+    void* d_board = nullptr;          // batched board results + ids
     // last call
     int last_w = 0, last_h = 0, last_frames = 0, last_nthr = 1;
     const uint8_t* last_gray = nullptr;
@@ -128,7 +129,7 @@ static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -760,6 +761,34 @@ int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t 
     launch_warp_only(h->stream, dev, g, h->d_small_f, size, h->d_patch);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->d_patch, (size_t)size * size, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* ids, const float* obj, int nboard, int info_type, const float* K,
+                                const float* dist, int ndist, float marker_size, float repj_err_thres, int y_perp, arucohip_board_t* out, float* prob) {
+    if (!h || !out || !prob) return ARUCOHIP_E_INVALID;
+    if (nboard <= 0 || !ids || !obj) return fail(h, ARUCOHIP_E_BOARD_CONFIG, "invalid BoardConfig that is empty");
+    if (nframes < 1 || nframes > h->last_frames) return fail(h, ARUCOHIP_E_INVALID, "nframes exceeds the last batch");
+    if (nboard * 12 > 8192) return fail(h, ARUCOHIP_E_CAPACITY, "board with too many markers");
+    HIPCHK(h, hipSetDevice(h->device));
+    float zeros[4] = {0, 0, 0, 0};
+    if (!dist || ndist == 0) dist = zeros, ndist = 4;
+    CamModel cam;
+    int rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam);
+    if (rc) return rc;
+    if (!h->d_board) {
+        HIPCHK(h, hipMalloc((void**)&h->d_board, (size_t)h->lim.max_batch * (sizeof(arucohip_board_t) + sizeof(float)) + 8192 * sizeof(int32_t)));
+    }
+    arucohip_board_t* d_out = (arucohip_board_t*)h->d_board;
+    float* d_prob = (float*)(d_out + h->lim.max_batch);
+    int32_t* d_ids = (int32_t*)(d_prob + h->lim.max_batch);
+    HIPCHK(h, hipMemcpyAsync(d_ids, ids, (size_t)nboard * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_small_f, obj, (size_t)nboard * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    launch_board_pose(h->stream, nframes, h->buf, d_ids, h->d_small_f, nboard, info_type, marker_size, repj_err_thres, cam, d_out, d_prob);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)nframes * sizeof(arucohip_board_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(prob, d_prob, (size_t)nframes * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ARUCOHIP_OK;
 }

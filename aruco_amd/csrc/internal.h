@@ -143,5 +143,7 @@ void launch_warp_only(hipStream_t s, const uint8_t* gray, const FrameGeom& g, co
 void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out);
 void launch_project_points(hipStream_t s, const float* obj, int npts, const double* rt, const CamModel& cam, float* img_out);
 void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const CamModel& cam);
+void launch_board_pose(hipStream_t s, int nframes, const Buffers& b, const int32_t* ids, const float* obj, int nboard, int info_type,
+                       float marker_size, float repj_thres, const CamModel& cam, arucohip_board_t* out, float* prob);
 
 }  // namespace ah

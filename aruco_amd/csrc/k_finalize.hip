@@ -164,6 +164,109 @@ void launch_project_points(hipStream_t s, const float* obj, int npts, const doub
     hipLaunchKernelGGL(project_points_kernel, dim3((npts + 63) / 64), dim3(64), 0, s, obj, npts, rt, cam, img_out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched BoardDetector::detect (boarddetector.cpp:90-205): one wavefront per frame on the device-resident markers of the
+// last batch. Lane 0 filters the markers by board id and lays out the 3-D / 2-D correspondences in LDS, then the 64 lanes
+// share the points of the planar solvePnP (wave sums for J^T J); optional reprojection filter and second solve.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_BOARD_POINTS = 512;
+
+struct BoardArgs {
+    const arucohip_marker_t* markers;
+    const int32_t* nmarkers;
+    int cap_markers;
+    const int32_t* ids;
+    const float* obj;      // nboard * 4 * 3
+    int nboard, info_type;
+    float marker_size, repj_thres;
+    CamModel cam;
+    arucohip_board_t* out;
+    float* prob;
+};
+
+__global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
+    __shared__ float s_obj[MAX_BOARD_POINTS * 3], s_img[MAX_BOARD_POINTS * 2], s_obj2[MAX_BOARD_POINTS * 3], s_img2[MAX_BOARD_POINTS * 2];
+    __shared__ int s_npts, s_nmark, s_n2;
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const arucohip_marker_t* M = a.markers + (size_t)frame * a.cap_markers;
+    const int nm = min(a.nmarkers[frame], a.cap_markers);
+    if (lane == 0) {
+        const float dx = a.obj[0] - a.obj[3], dy = a.obj[1] - a.obj[4], dz = a.obj[2] - a.obj[5];
+        const double side = sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+        const double mpp = a.info_type == ARUCOHIP_BOARD_PIX ? (double)a.marker_size / side : 1.0;
+        int np = 0, nk = 0;
+        for (int i = 0; i < nm; i++) {
+            int slot = -1;
+            for (int j = 0; j < a.nboard; j++)
+                if (a.ids[j] == M[i].id) {
+                    slot = j;
+                    break;
+                }
+            if (slot < 0) continue;
+            nk++;
+            if (np + 4 > MAX_BOARD_POINTS) continue;
+            for (int p = 0; p < 4; p++, np++) {
+                s_img[2 * np] = M[i].corners[2 * p], s_img[2 * np + 1] = M[i].corners[2 * p + 1];
+                const float* q = a.obj + ((size_t)slot * 4 + p) * 3;
+                for (int c = 0; c < 3; c++) s_obj[3 * np + c] = (float)(q[c] * mpp);
+            }
+        }
+        s_npts = np, s_nmark = nk;
+    }
+    __syncthreads();
+    const int np = s_npts, nk = s_nmark;
+    arucohip_board_t res;
+    res.n_markers = nk, res.has_pose = 0;
+    for (int k = 0; k < 3; k++) res.rvec[k] = res.tvec[k] = 0;
+    float prob = 0;
+    const bool enough = (a.marker_size > 0 && a.info_type == ARUCOHIP_BOARD_PIX) || a.info_type == ARUCOHIP_BOARD_METERS;
+    if (nk > 0 && a.cam.has_K && enough) {
+        double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+        bool ok = solve_pnp_planar_wave(s_obj, s_img, np, a.cam, r, t, lane);
+        if (a.repj_thres > 0 && ok) {
+            double R[9];
+            rodrigues_vec2mat(r, R, nullptr);
+            if (lane == 0) s_n2 = 0;
+            __syncthreads();
+            for (int base = 0; base < np; base += 64) {   // order-preserving compaction of the points that pass
+                const int i = base + lane;
+                bool keep = false;
+                if (i < np) {
+                    double mx, my;
+                    project_point(s_obj[3 * i], s_obj[3 * i + 1], s_obj[3 * i + 2], R, nullptr, t, a.cam.K, a.cam.k, &mx, &my, nullptr, nullptr);
+                    const float ex = (float)mx - s_img[2 * i], ey = (float)my - s_img[2 * i + 1];
+                    keep = (float)sqrt((double)ex * ex + (double)ey * ey) < a.repj_thres;
+                }
+                const unsigned long long bal = __ballot(keep);
+                const int dst = s_n2 + __popcll(bal & ((1ull << lane) - 1ull));
+                if (keep) {
+                    for (int c = 0; c < 3; c++) s_obj2[3 * dst + c] = s_obj[3 * i + c];
+                    s_img2[2 * dst] = s_img[2 * i], s_img2[2 * dst + 1] = s_img[2 * i + 1];
+                }
+                __syncthreads();
+                if (lane == 0) s_n2 += __popcll(bal);
+                __syncthreads();
+            }
+            // fewer than 4 surviving points: the reference's second solvePnP would throw; keep the first pose, flag no pose
+            ok = s_n2 >= 4 && solve_pnp_planar_wave(s_obj2, s_img2, s_n2, a.cam, r, t, lane);
+        }
+        if (ok && a.cam.y_perp) rotate_x_axis(r);
+        res.has_pose = ok ? 1 : 0;
+        for (int k = 0; k < 3; k++) res.rvec[k] = r[k], res.tvec[k] = t[k];
+        prob = (float)nk / (float)a.nboard;
+    }
+    if (lane == 0) a.out[frame] = res, a.prob[frame] = prob;
+}
+
+void launch_board_pose(hipStream_t s, int nframes, const Buffers& b, const int32_t* ids, const float* obj, int nboard, int info_type,
+                       float marker_size, float repj_thres, const CamModel& cam, arucohip_board_t* out, float* prob) {
+    BoardArgs a;
+    a.markers = b.markers, a.nmarkers = b.nmarkers, a.cap_markers = b.cap_markers;
+    a.ids = ids, a.obj = obj, a.nboard = nboard, a.info_type = info_type, a.marker_size = marker_size, a.repj_thres = repj_thres;
+    a.cam = cam, a.out = out, a.prob = prob;
+    hipLaunchKernelGGL(board_pose_kernel, dim3(nframes), dim3(64), 0, s, a);
+}
+
 // rotateXAxis on a pose stored as rt[0..2]
 __global__ void rotate_x_kernel(double* rt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) rotate_x_axis(rt);

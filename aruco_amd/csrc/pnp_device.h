@@ -339,6 +339,160 @@ __device__ inline bool solve_pnp_planar(const float* obj, const float* img, int 
     return true;
 }
 
+// Wave-parallel form of solve_pnp_planar for many points (board pose): the 64 lanes of one wave split the points, every
+// accumulation is followed by a butterfly sum so that all lanes hold the same totals and run the small solves redundantly.
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline void wave_sum_arr(double* a, int n) {
+    for (int i = 0; i < n; i++) a[i] = wave_sum_d(a[i]);
+}
+
+__device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img, int n, const CamModel& cam, double* rvec, double* tvec, int lane) {
+    if (n < 4) return false;
+    const float* K = cam.K;
+    const double* k = cam.k;
+    double Mc[2] = {0, 0};
+    bool nonplanar = false;
+    for (int i = lane; i < n; i += 64) {
+        if (obj[3 * i + 2] != 0.f) nonplanar = true;
+        Mc[0] += (double)obj[3 * i], Mc[1] += (double)obj[3 * i + 1];
+    }
+    if (__any(nonplanar)) return false;
+    wave_sum_arr(Mc, 2);
+    Mc[0] /= n, Mc[1] /= n;
+    // ---- homography plane -> normalised image (inputs rounded to float as cv::findHomography does)
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = lane; i < n; i += 64) {
+        double ux, uy;
+        undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
+        cM[0] += (double)(float)((double)obj[3 * i] - Mc[0]), cM[1] += (double)(float)((double)obj[3 * i + 1] - Mc[1]);
+        cm[0] += (double)(float)ux, cm[1] += (double)(float)uy;
+    }
+    wave_sum_arr(cM, 2), wave_sum_arr(cm, 2);
+    cM[0] /= n, cM[1] /= n, cm[0] /= n, cm[1] /= n;
+    for (int i = lane; i < n; i += 64) {
+        double ux, uy;
+        undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
+        sM[0] += fabs((double)(float)((double)obj[3 * i] - Mc[0]) - cM[0]);
+        sM[1] += fabs((double)(float)((double)obj[3 * i + 1] - Mc[1]) - cM[1]);
+        sm[0] += fabs((double)(float)ux - cm[0]), sm[1] += fabs((double)(float)uy - cm[1]);
+    }
+    wave_sum_arr(sM, 2), wave_sum_arr(sm, 2);
+    double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    bool hok = !(fabs(sM[0]) < DBL_EPSILON || fabs(sM[1]) < DBL_EPSILON || fabs(sm[0]) < DBL_EPSILON || fabs(sm[1]) < DBL_EPSILON);
+    double H[9];
+    if (hok) {
+        sM[0] = n / sM[0], sM[1] = n / sM[1], sm[0] = n / sm[0], sm[1] = n / sm[1];
+        double A[64], b[8];
+        for (int i = 0; i < 64; i++) A[i] = 0;
+        for (int i = 0; i < 8; i++) b[i] = 0;
+        for (int i = lane; i < n; i += 64) {
+            double ux, uy;
+            undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
+            double x = ((double)(float)ux - cm[0]) * sm[0], y = ((double)(float)uy - cm[1]) * sm[1];
+            double X = ((double)(float)((double)obj[3 * i] - Mc[0]) - cM[0]) * sM[0];
+            double Y = ((double)(float)((double)obj[3 * i + 1] - Mc[1]) - cM[1]) * sM[1];
+            double Lx[8] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y};
+            double Ly[8] = {0, 0, 0, X, Y, 1, -y * X, -y * Y};
+            for (int j = 0; j < 8; j++) {
+                for (int q = 0; q < 8; q++) A[j * 8 + q] += Lx[j] * Lx[q] + Ly[j] * Ly[q];
+                b[j] += Lx[j] * x + Ly[j] * y;
+            }
+        }
+        wave_sum_arr(A, 64), wave_sum_arr(b, 8);
+        hok = solve_n(A, b, 8);
+        if (hok) {
+            double H0[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
+            double invHnorm[9] = {1. / sm[0], 0, cm[0], 0, 1. / sm[1], cm[1], 0, 0, 1};
+            double Hnorm2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+            double T[9];
+            mat3_mul(invHnorm, H0, T);
+            mat3_mul(T, Hnorm2, H);
+            double s = 1. / H[8];
+            for (int i = 0; i < 9; i++) {
+                H[i] *= s;
+                if (!isfinite(H[i])) hok = false;
+            }
+        }
+    }
+    if (hok) {
+        double h1n = sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]);
+        double h2n = sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+        double s1 = 1. / fmax(h1n, DBL_EPSILON), s2 = 1. / fmax(h2n, DBL_EPSILON), st = 2. / fmax(h1n + h2n, DBL_EPSILON);
+        double h1[3] = {H[0] * s1, H[3] * s1, H[6] * s1}, h2[3] = {H[1] * s2, H[4] * s2, H[7] * s2};
+        t[0] = H[2] * st, t[1] = H[5] * st, t[2] = H[8] * st;
+        double h3[3] = {h1[1] * h2[2] - h1[2] * h2[1], h1[2] * h2[0] - h1[0] * h2[2], h1[0] * h2[1] - h1[1] * h2[0]};
+        double R[9] = {h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2]};
+        rodrigues_mat2vec(R, r);
+        rodrigues_vec2mat(r, R, nullptr);
+        for (int i = 0; i < 3; i++) t[i] += R[i * 3] * (-Mc[0]) + R[i * 3 + 1] * (-Mc[1]);
+        rodrigues_mat2vec(R, r);
+    }
+    // ---- CvLevMarq
+    double param[6] = {r[0], r[1], r[2], t[0], t[1], t[2]}, prev[6];
+    double JtJ[36], JtErr[6];
+    int lambdaLg10 = -3, iters = 0;
+    double prevErrNorm = DBL_MAX;
+    for (;;) {
+        double R[9], dRdr[27];
+        rodrigues_vec2mat(param, R, dRdr);
+        for (int i = 0; i < 36; i++) JtJ[i] = 0;
+        for (int i = 0; i < 6; i++) JtErr[i] = 0;
+        double e2 = 0;
+        for (int i = lane; i < n; i += 64) {
+            double mx, my, dr[6], dt[6];
+            project_point(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], R, dRdr, param + 3, K, k, &mx, &my, dr, dt);
+            double ex = mx - (double)img[2 * i], ey = my - (double)img[2 * i + 1];
+            double jx[6] = {dr[0], dr[1], dr[2], dt[0], dt[1], dt[2]};
+            double jy[6] = {dr[3], dr[4], dr[5], dt[3], dt[4], dt[5]};
+            for (int a = 0; a < 6; a++) {
+                for (int c = 0; c < 6; c++) JtJ[a * 6 + c] += jx[a] * jx[c] + jy[a] * jy[c];
+                JtErr[a] += jx[a] * ex + jy[a] * ey;
+            }
+            e2 += ex * ex + ey * ey;
+        }
+        wave_sum_arr(JtJ, 36), wave_sum_arr(JtErr, 6);
+        e2 = wave_sum_d(e2);
+        for (int i = 0; i < 6; i++) prev[i] = param[i];
+        if (iters == 0) prevErrNorm = sqrt(e2);
+        double errNorm;
+        for (bool first = true;; first = false) {
+            if (!first) {
+                if (!(errNorm > prevErrNorm && ++lambdaLg10 <= 16)) break;
+            }
+            double lambda = exp(lambdaLg10 * log(10.));
+            double A[36], b[6];
+            for (int i = 0; i < 36; i++) A[i] = JtJ[i];
+            for (int i = 0; i < 6; i++) b[i] = JtErr[i];
+            for (int i = 0; i < 6; i++) A[i * 7] *= 1. + lambda;
+            if (!solve_n(A, b, 6))
+                for (int i = 0; i < 6; i++) b[i] = 0;
+            for (int i = 0; i < 6; i++) param[i] = prev[i] - b[i];
+            rodrigues_vec2mat(param, R, nullptr);
+            e2 = 0;
+            for (int i = lane; i < n; i += 64) {
+                double mx, my;
+                project_point(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], R, nullptr, param + 3, K, k, &mx, &my, nullptr, nullptr);
+                double ex = mx - (double)img[2 * i], ey = my - (double)img[2 * i + 1];
+                e2 += ex * ex + ey * ey;
+            }
+            e2 = wave_sum_d(e2);
+            errNorm = sqrt(e2);
+        }
+        lambdaLg10 = max(lambdaLg10 - 1, -16);
+        double num = 0, den = 0;
+        for (int i = 0; i < 6; i++) num += (param[i] - prev[i]) * (param[i] - prev[i]), den += prev[i] * prev[i];
+        double change = sqrt(num) / sqrt(den);
+        if (++iters >= 20 || change < FLT_EPSILON) break;
+        prevErrNorm = errNorm;
+    }
+    for (int i = 0; i < 3; i++) rvec[i] = param[i], tvec[i] = param[3 + i];
+    return true;
+}
+
 // aruco::rotateXAxis — rotation in float (cv::Matx33f), result kept at float precision
 __device__ inline void rotate_x_axis(double* rvec) {
     double Rd[9];

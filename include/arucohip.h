@@ -166,6 +166,13 @@ int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, 
                           float repj_err_thres, int y_perpendicular, arucohip_marker_t* out_markers, arucohip_board_t* out,
                           float* prob);
 
+/* BoardDetector::detect for every frame of the LAST arucohip_detect_batch call, on its device-resident markers (one
+ * wavefront per frame, wave-parallel solvePnP over all board corners). out / prob: host arrays of nframes entries. The
+ * board's member markers are the detected markers whose id is in `ids`, in the same order. */
+int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* ids, const float* obj, int nboard, int info_type,
+                                const float* K, const float* dist, int ndist, float marker_size, float repj_err_thres,
+                                int y_perpendicular, arucohip_board_t* out, float* prob);
+
 /* Marker::calculateExtrinsics (marker.h:98-104 / marker.cpp:112-124) for n markers at once (batched solvePnP). */
 int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers, int n, const float* K, const float* dist,
                                   int ndist, float marker_size, int y_perpendicular);

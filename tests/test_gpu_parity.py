@@ -312,20 +312,29 @@ def test_4k_board_frames(env):
     try:
         frames = []
         for f in range(2):
-            rvec = np.array([np.pi, 0, 0]) + rng.uniform(-0.2, 0.2, 3)
+            rvec = rng.uniform(-0.2, 0.2, 3)   # board_pix.yml: x right, y down, z away from the camera
             tvec = np.array([rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(0.52, 0.60)])
             fr, quads = synth.render_board(bc["ids"], bc["obj"], K.astype(float), rvec, tvec, W, H, rng, device="cuda",
                                            unit=0.039 / 100.0)
             frames.append(fr.cpu().numpy())
         got = h.detect_batch_host(np.stack(frames))
+        batched = h.board_detect_batch(2, bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039)
+        batched_f = h.board_detect_batch(2, bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039, repj_err_thres=4.0, y_perp=True)
         o = orc.Oracle()
         for f in range(2):
             ref = o.detect(frames[f])
-            assert len(ref) >= 20
+            assert len(ref) >= 20 and set(m["id"] for m in ref) <= set(bc["ids"])
             _compare_markers(got[f], ref)
             b = h.board_detect(got[f], bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039)
             ob = orc.board_detect(ref, bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039)
             assert b["has_pose"] == 1 and abs(b["prob"] - ob["prob"]) < 1e-6
             assert rel_err(b["rvec"], ob["rvec"]) < POSE_REL_TOL and rel_err(b["tvec"], ob["tvec"]) < POSE_REL_TOL
+            # batched wave-parallel board pose == per-frame call == oracle
+            bb = batched[f]
+            assert bb["has_pose"] == 1 and bb["n_markers"] == len(ob["markers"]) and abs(bb["prob"] - ob["prob"]) < 1e-6
+            assert rel_err(bb["rvec"], ob["rvec"]) < POSE_REL_TOL and rel_err(bb["tvec"], ob["tvec"]) < POSE_REL_TOL
+            of = orc.board_detect(ref, bc["ids"], bc["obj"], bc["info_type"], K.reshape(-1), dist, 0.039, 4.0, True)
+            assert batched_f[f]["has_pose"] == of["has_pose"] == 1
+            assert rel_err(batched_f[f]["rvec"], of["rvec"]) < POSE_REL_TOL and rel_err(batched_f[f]["tvec"], of["tvec"]) < POSE_REL_TOL
     finally:
         h.close()
