@@ -220,6 +220,14 @@ class Handle:
                                                _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
                                                C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1))
 
+    def detect_batch_mixed(self, frames_host_ptr, nframes, width, height, out_ptr, cap, n_out_ptr, K=None, dist=None,
+                           marker_size=-1.0, y_perp=False):
+        """Frames in (pinned) host memory, results left on the device: the PCIe-inclusive path."""
+        Ka, da = _f32(K), _f32(dist)
+        self._chk(self.L.arucohip_detect_batch(self.h, C.c_void_p(frames_host_ptr), nframes, width, height, width, width * height, 0,
+                                               _ptr(Ka), _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
+                                               C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1))
+
     def batch_status(self):
         return self._chk(self.L.arucohip_batch_status(self.h))
 

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
     const bool enough = (a.marker_size > 0 && a.info_type == ARUCOHIP_BOARD_PIX) || a.info_type == ARUCOHIP_BOARD_METERS;
     if (nk > 0 && a.cam.has_K && enough) {
         double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
-        bool ok = solve_pnp_planar_wave(s_obj, s_img, np, a.cam, r, t, lane);
+        bool ok = solve_pnp_planar_wave<64>(s_obj, s_img, np, a.cam, r, t, lane);
         if (a.repj_thres > 0 && ok) {
             double R[9];
             rodrigues_vec2mat(r, R, nullptr);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
                 __syncthreads();
             }
             // fewer than 4 surviving points: the reference's second solvePnP would throw; keep the first pose, flag no pose
-            ok = s_n2 >= 4 && solve_pnp_planar_wave(s_obj2, s_img2, s_n2, a.cam, r, t, lane);
+            ok = s_n2 >= 4 && solve_pnp_planar_wave<64>(s_obj2, s_img2, s_n2, a.cam, r, t, lane);
         }
         if (ok && a.cam.y_perp) rotate_x_axis(r);
         res.has_pose = ok ? 1 : 0;

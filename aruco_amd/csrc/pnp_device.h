@@ -12,36 +12,57 @@
 
 namespace ah {
 
-__device__ inline bool solve_n(double* A, double* b, int n) {
-    for (int c = 0; c < n; c++) {
+// Gaussian elimination with partial pivoting, same operation order as the CPU oracle. N is a template parameter and every
+// loop is unrolled, the pivot row is exchanged by selects, so A and b are indexed statically and stay in registers (a
+// run-time indexed private array would live in scratch memory: one memory round trip per element access).
+template <int N>
+__device__ inline bool solve_static(double* A, double* b) {
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
         int piv = c;
-        double best = fabs(A[c * n + c]);
-        for (int r = c + 1; r < n; r++)
-            if (fabs(A[r * n + c]) > best) best = fabs(A[r * n + c]), piv = r;
-        if (best == 0) return false;
-        if (piv != c) {
-            for (int k = 0; k < n; k++) {
-                double t = A[c * n + k];
-                A[c * n + k] = A[piv * n + k];
-                A[piv * n + k] = t;
-            }
-            double t = b[c];
-            b[c] = b[piv];
-            b[piv] = t;
+        double best = fabs(A[c * N + c]);
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const double v = fabs(A[r * N + c]);
+            if (v > best) best = v, piv = r;
         }
-        double inv = 1.0 / A[c * n + c];
-        for (int r = c + 1; r < n; r++) {
-            double f = A[r * n + c] * inv;
-            for (int k = c; k < n; k++) A[r * n + k] -= f * A[c * n + k];
+        if (best == 0) ok = false;
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const double t = A[c * N + k], u = A[r * N + k];
+                A[c * N + k] = sw ? u : t;
+                A[r * N + k] = sw ? t : u;
+            }
+            const double t = b[c], u = b[r];
+            b[c] = sw ? u : t;
+            b[r] = sw ? t : u;
+        }
+        const double inv = 1.0 / A[c * N + c];
+#pragma unroll
+        for (int r = c + 1; r < N; r++) {
+            const double f = A[r * N + c] * inv;
+#pragma unroll
+            for (int k = c; k < N; k++) A[r * N + k] -= f * A[c * N + k];
             b[r] -= f * b[c];
         }
     }
-    for (int r = n - 1; r >= 0; r--) {
+#pragma unroll
+    for (int r = N - 1; r >= 0; r--) {
         double s = b[r];
-        for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
-        b[r] = s / A[r * n + r];
+#pragma unroll
+        for (int k = r + 1; k < N; k++) s -= A[r * N + k] * b[k];
+        b[r] = s / A[r * N + r];
     }
-    return true;
+    return ok;
+}
+
+__device__ inline bool solve_n(double* A, double* b, int n) {
+    if (n == 6) return solve_static<6>(A, b);
+    return solve_static<8>(A, b);
 }
 
 __device__ inline void mat3_mul(const double* A, const double* B, double* C) {
@@ -341,46 +362,50 @@ __device__ inline bool solve_pnp_planar(const float* obj, const float* img, int 
 
 // Wave-parallel form of solve_pnp_planar for many points (board pose): the 64 lanes of one wave split the points, every
 // accumulation is followed by a butterfly sum so that all lanes hold the same totals and run the small solves redundantly.
+// G = lanes that share one problem (a power of two: 64 = the whole wave for a board, 4 = one lane per marker corner)
+template <int G>
 __device__ inline double wave_sum_d(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+template <int G>
 __device__ inline void wave_sum_arr(double* a, int n) {
-    for (int i = 0; i < n; i++) a[i] = wave_sum_d(a[i]);
+    for (int i = 0; i < n; i++) a[i] = wave_sum_d<G>(a[i]);
 }
 
+template <int G>
 __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img, int n, const CamModel& cam, double* rvec, double* tvec, int lane) {
     if (n < 4) return false;
     const float* K = cam.K;
     const double* k = cam.k;
     double Mc[2] = {0, 0};
     bool nonplanar = false;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += G) {
         if (obj[3 * i + 2] != 0.f) nonplanar = true;
         Mc[0] += (double)obj[3 * i], Mc[1] += (double)obj[3 * i + 1];
     }
-    if (__any(nonplanar)) return false;
-    wave_sum_arr(Mc, 2);
+    if (wave_sum_d<G>(nonplanar ? 1.0 : 0.0) > 0) return false;
+    wave_sum_arr<G>(Mc, 2);
     Mc[0] /= n, Mc[1] /= n;
     // ---- homography plane -> normalised image (inputs rounded to float as cv::findHomography does)
     double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += G) {
         double ux, uy;
         undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
         cM[0] += (double)(float)((double)obj[3 * i] - Mc[0]), cM[1] += (double)(float)((double)obj[3 * i + 1] - Mc[1]);
         cm[0] += (double)(float)ux, cm[1] += (double)(float)uy;
     }
-    wave_sum_arr(cM, 2), wave_sum_arr(cm, 2);
+    wave_sum_arr<G>(cM, 2), wave_sum_arr<G>(cm, 2);
     cM[0] /= n, cM[1] /= n, cm[0] /= n, cm[1] /= n;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += G) {
         double ux, uy;
         undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
         sM[0] += fabs((double)(float)((double)obj[3 * i] - Mc[0]) - cM[0]);
         sM[1] += fabs((double)(float)((double)obj[3 * i + 1] - Mc[1]) - cM[1]);
         sm[0] += fabs((double)(float)ux - cm[0]), sm[1] += fabs((double)(float)uy - cm[1]);
     }
-    wave_sum_arr(sM, 2), wave_sum_arr(sm, 2);
+    wave_sum_arr<G>(sM, 2), wave_sum_arr<G>(sm, 2);
     double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
     bool hok = !(fabs(sM[0]) < DBL_EPSILON || fabs(sM[1]) < DBL_EPSILON || fabs(sm[0]) < DBL_EPSILON || fabs(sm[1]) < DBL_EPSILON);
     double H[9];
@@ -389,7 +414,7 @@ __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img,
         double A[64], b[8];
         for (int i = 0; i < 64; i++) A[i] = 0;
         for (int i = 0; i < 8; i++) b[i] = 0;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += G) {
             double ux, uy;
             undistort_point(img[2 * i], img[2 * i + 1], K, k, &ux, &uy);
             double x = ((double)(float)ux - cm[0]) * sm[0], y = ((double)(float)uy - cm[1]) * sm[1];
@@ -402,7 +427,7 @@ __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img,
                 b[j] += Lx[j] * x + Ly[j] * y;
             }
         }
-        wave_sum_arr(A, 64), wave_sum_arr(b, 8);
+        wave_sum_arr<G>(A, 64), wave_sum_arr<G>(b, 8);
         hok = solve_n(A, b, 8);
         if (hok) {
             double H0[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
@@ -442,7 +467,7 @@ __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img,
         for (int i = 0; i < 36; i++) JtJ[i] = 0;
         for (int i = 0; i < 6; i++) JtErr[i] = 0;
         double e2 = 0;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += G) {
             double mx, my, dr[6], dt[6];
             project_point(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], R, dRdr, param + 3, K, k, &mx, &my, dr, dt);
             double ex = mx - (double)img[2 * i], ey = my - (double)img[2 * i + 1];
@@ -454,8 +479,8 @@ __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img,
             }
             e2 += ex * ex + ey * ey;
         }
-        wave_sum_arr(JtJ, 36), wave_sum_arr(JtErr, 6);
-        e2 = wave_sum_d(e2);
+        wave_sum_arr<G>(JtJ, 36), wave_sum_arr<G>(JtErr, 6);
+        e2 = wave_sum_d<G>(e2);
         for (int i = 0; i < 6; i++) prev[i] = param[i];
         if (iters == 0) prevErrNorm = sqrt(e2);
         double errNorm;
@@ -473,13 +498,13 @@ __device__ inline bool solve_pnp_planar_wave(const float* obj, const float* img,
             for (int i = 0; i < 6; i++) param[i] = prev[i] - b[i];
             rodrigues_vec2mat(param, R, nullptr);
             e2 = 0;
-            for (int i = lane; i < n; i += 64) {
+            for (int i = lane; i < n; i += G) {
                 double mx, my;
                 project_point(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], R, nullptr, param + 3, K, k, &mx, &my, nullptr, nullptr);
                 double ex = mx - (double)img[2 * i], ey = my - (double)img[2 * i + 1];
                 e2 += ex * ex + ey * ey;
             }
-            e2 = wave_sum_d(e2);
+            e2 = wave_sum_d<G>(e2);
             errNorm = sqrt(e2);
         }
         lambdaLg10 = max(lambdaLg10 - 1, -16);

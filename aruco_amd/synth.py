@@ -229,3 +229,20 @@ def render_board(ids, obj, K, rvec, tvec, width, height, rng, device="cpu", nois
         gen.manual_seed(int(rng.randint(0, 2 ** 31 - 1)))
         img = img + torch.randn(img.shape, generator=gen, device=dev) * noise_sigma
     return img.round().clamp(0, 255).to(torch.uint8), quads
+
+
+def make_board_stream(n_frames, ids, obj, K, width=3840, height=2160, seed=4711, device="cpu", unit=0.039 / 100.0,
+                      z_range=(0.52, 0.60), noise_sigma=1.5):
+    """Config-4 stream: the board (ids, obj[N][4][3] in board units) seen through random poses (board x right, y down,
+    z away from the camera, as testdata/board/board_pix.yml defines it). Returns (frames uint8 [N,H,W], poses)."""
+    rng = np.random.RandomState(seed)
+    frames = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)
+    poses = []
+    for f in range(n_frames):
+        rvec = rng.uniform(-0.2, 0.2, 3)
+        tvec = np.array([rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(*z_range)])
+        fr, _ = render_board(ids, obj, np.asarray(K, float).reshape(3, 3), rvec, tvec, width, height, rng, device=device,
+                             noise_sigma=noise_sigma, unit=unit)
+        frames[f] = fr
+        poses.append((rvec, tvec))
+    return frames, poses

@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="frames per step and GPU")
     ap.add_argument("--frames", type=int, default=1024, help="distinct synthetic frames per GPU (SURVEY.md config 2: N=1024)")
     ap.add_argument("--pose", action="store_true", help="config 3: intrinsics + per-marker solvePnP")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
+                         "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
+    ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,8 +101,34 @@ def main():
     from aruco_amd import dist as adist
 
     capi.load()
+    if args.config == 3:
+        args.pose = True
+    global W, H, ALG_BYTES_PER_FRAME
+    board = None
+    if args.config == 4:
+        W, H = 3840, 2160
+        ALG_BYTES_PER_FRAME = 3 * W * H
+        if args.frames == 1024:
+            args.frames = 128       # 4K frames are 4x larger; 128 distinct frames per GPU by default
+        if args.batch == 1024:
+            args.batch = 128
+        from tests.util import load_case
+        _, doc = load_case("board")
+        board = doc["board_conf"]
+        K0 = np.array(doc["intrinsics"]["K"], np.float32).reshape(3, 3)   # CameraParameters::resize rule to 4K
+        K0[0, 0] *= np.float32(W / 640.0); K0[0, 2] *= np.float32(W / 640.0)
+        K0[1, 1] *= np.float32(H / 480.0); K0[1, 2] *= np.float32(H / 480.0)
+        board["K"] = K0.reshape(-1)
     B = min(args.batch, args.frames)
-    frames, truth = synth.make_stream(args.frames, width=W, height=H, seed=4711 + rank, device=dev)
+    if board is None:
+        frames, truth = synth.make_stream(args.frames, width=W, height=H, seed=4711 + rank, device=dev)
+    else:
+        frames, _ = synth.make_board_stream(args.frames, board["ids"], board["obj"], board["K"], width=W, height=H, seed=4711 + rank, device=dev)
+        truth = [[{"id": i} for i in board["ids"]] for _ in range(args.frames)]
+    frames_host = None
+    if args.host_frames:
+        frames_host = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
+        frames_host.copy_(frames)
     handle = capi.Handle(W, H, max_batch=B, device=local_rank)
     stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream shared by the library, its events and RCCL
     torch.cuda.set_stream(stream)
@@ -110,10 +140,18 @@ def main():
     msize = 0.05 if args.pose else -1.0
     nwin = max(args.frames // B, 1)
 
+    boards = []
+
     def step(i):
         off = (i % nwin) * B
-        handle.detect_batch_device(frames[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
-                                   marker_size=msize)
+        if frames_host is not None:   # H2D of the batch is part of the step
+            handle.detect_batch_mixed(frames_host[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
+                                      marker_size=msize)
+        else:
+            handle.detect_batch_device(frames[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
+                                       marker_size=msize)
+        if board is not None:
+            boards[:] = handle.board_detect_batch(B, board["ids"], board["obj"], board["info_type"], board["K"], [0.0] * 5, 0.039)
         if world > 1:
             return adist.gather_marker_blocks(out, cnt, dst=0)
         return None
@@ -151,6 +189,8 @@ def main():
     rendered = sum(len(truth[off + f]) for f in range(B))
     if found < 0.9 * rendered:
         raise SystemExit("only %d of %d rendered markers detected" % (found, rendered))
+    if board is not None and sum(b["has_pose"] for b in boards) < 0.95 * B:
+        raise SystemExit("board pose missing on some frames")
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -168,12 +208,14 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "frames/sec at 1920x1080", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec at %dx%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 synthetic stream, ~20 markers/frame, threshold+contour+decode+LINES"
-                                   + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"),
-                       "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 20,
+            "config": {"workload": ("3840x2160 6x4 board frames (24 markers), detect + batched BoardDetector solvePnP (config 4)" if board is not None else
+                                    "1920x1080 synthetic stream, ~20 markers/frame, threshold+contour+decode+LINES"
+                                    + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
+                                   + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else ""),
+                       "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
                        "markers_detected_per_frame": round(found / B, 2), "parallelism": "frames sharded 1 stream/GPU"
                        + (", RCCL gather of marker blocks per step" if world > 1 else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
