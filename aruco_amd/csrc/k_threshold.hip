@@ -24,7 +24,7 @@ enum ThrMode { MODE_ADPT = 0, MODE_FIXED = 1, MODE_BINARY = 2 };
 
 constexpr int STRIP_OUT = 224;   // output pixels per strip (7 words)
 constexpr int STRIP_HALO = 16;   // halo pixels per side (4 lanes) — covers box radius <= 15 plus the 1-px neighbourhood
-constexpr int SEG = 64;          // output rows per wave
+constexpr int SEG = 128;         // output rows per wave
 constexpr int LOCAL_TRIG = 256;
 
 struct ThrArgs {
@@ -46,6 +46,11 @@ struct ThrArgs {
 };
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xFFu; }
+
+// value of the neighbouring lane through the DPP wave shift (a VALU operand modifier on gfx9, no LDS crossbar trip):
+// from_left = lane i receives lane i-1 (wave_shr:1), from_right = lane i receives lane i+1 (wave_shl:1); lane 0 / 63 get 0
+__device__ __forceinline__ uint32_t from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
 
 template <int R, int MODE>
 __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
@@ -108,8 +113,8 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
                 Dn[NL] = D0;
 #pragma unroll
                 for (int q = 1; q <= NL; q++) {
-                    Dn[NL - q] = __shfl_up(D0, q, 64);
-                    Dn[NL + q] = __shfl_down(D0, q, 64);
+                    Dn[NL - q] = from_left(Dn[NL - q + 1]);     // lane i - q
+                    Dn[NL + q] = from_right(Dn[NL + q - 1]);    // lane i + q
                 }
                 auto px = [&](int i) -> uint32_t {   // byte i of the row relative to this lane's first pixel, i in [-4NL, 4NL+3]
                     const int q = i + 4 * NL;
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
             }
             // ---- binary row for contour purposes: frame cleared
             const uint32_t B = (c >= 1 && c <= H - 2) ? (tbits & insx) : 0u;
-            const uint32_t left = (__shfl_up(B, 1, 64) >> 3) & 1u, right = __shfl_down(B, 1, 64) & 1u;
+            const uint32_t Bnext = from_right(B);
+            const uint32_t left = (from_left(B) >> 3) & 1u, right = Bnext & 1u;
             const uint32_t Emid = left | (B << 1) | (right << 5);
             if (c >= ys) {   // c < ye by construction
                 if (MODE != MODE_BINARY && out_lane) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
                 }
                 // 8x8 tiles: an even lane and its right neighbour hold the 8 pixels of one tile row; a tile is stored
                 // every 8 rows (segments start on multiples of 8)
-                tile_acc |= (unsigned long long)(B | (__shfl_down(B, 1, 64) << 4)) << (8 * (c & 7));
+                tile_acc |= (unsigned long long)(B | (Bnext << 4)) << (8 * (c & 7));
                 if ((c & 7) == 7 || c == ye - 1) {
                     if (tile_lane) bdst[(size_t)(c >> 3) * a.tnx + (x >> 3)] = tile_acc;
                     tile_acc = 0;
