@@ -101,6 +101,8 @@ struct Buffers {
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
+    uint2* trig2;          // [P][cap_trig] candidates whose walk outlasted the first pass
+    uint32_t* trig2_cnt;   // [P * TRIG_CNT_STRIDE]
     ContourDesc* cdesc;
     short2* pool;
     uint32_t* walk_scratch; // checkpoint rings of the walker lanes

@@ -144,6 +144,10 @@ struct WalkArgs {
     uint32_t cap_trig, cap_cdesc, cap_pool;
     int width, height;
     int min_contour, max_contour;
+    int phase;             // 0: every candidate, at most soft_max steps, longer walks are queued; 1: the queued long walks
+    uint32_t soft_max;
+    uint2* trig2;          // [P][cap_trig] candidates of long walks (same two halves)
+    uint32_t* trig2_cnt;
     uint32_t* scratch;     // [lanes in the grid][maxck] private checkpoint ring of every walker lane
     short2* pool;          // checkpoints of a kept border are copied in front of its point range
     int maxck;
@@ -155,9 +159,13 @@ struct WalkArgs {
 template <bool HOLE>
 __device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chunk, int nchunks, uint32_t* rows) {
     const uint32_t half = a.cap_trig / 2;
-    const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
+    const uint32_t* cnt = a.phase ? a.trig2_cnt : a.trig_cnt;
+    const uint32_t ntrig = min(cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
     const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
-    const uint2* list = a.trig + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
+    const uint2* list = (a.phase ? a.trig2 : a.trig) + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
+    // Phase 0 gives every candidate a short leash: most walks (small borders, false starts) end within it and the few long
+    // ones are queued for phase 1, whose waves then hold long walks only instead of one long walk and 63 idle lanes.
+    const uint32_t leash = a.phase ? 0xFFFFFFFFu : a.soft_max;
     const int lane = threadIdx.x;
     uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
     const uint32_t nmax = (uint32_t)a.max_contour;
@@ -197,6 +205,13 @@ __device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chun
                 const uint32_t npos = pos + tb_dpos(d);
                 if (bad | (n >= nmax)) {
                     live = false;
+                } else if (n >= leash) {
+                    live = false;
+                    const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
+                    if (slot < half)
+                        a.trig2[(size_t)plane * a.cap_trig + (HOLE ? half : 0) + slot] = make_uint2(HOLE ? 1u : 0u, tkey);
+                    else
+                        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
                 } else if (npos == pos0 && pos == pos1) {
                     live = false, ok = true;
                 } else {
@@ -250,7 +265,12 @@ void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const Detect
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
+    a.trig2 = b.trig2, a.trig2_cnt = b.trig2_cnt;
+    a.soft_max = 96;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
+    a.phase = 0;
+    hipLaunchKernelGGL(walker_kernel, dim3(((nplanes + 7) / 8) * 8 * WALK_BLOCKS), dim3(64), 0, s, a);
+    a.phase = 1;
     hipLaunchKernelGGL(walker_kernel, dim3(((nplanes + 7) / 8) * 8 * WALK_BLOCKS), dim3(64), 0, s, a);
 }
 
