@@ -20,10 +20,13 @@ out = {"frames_per_launch": frames, "unit_note": "FETCH_SIZE / WRITE_SIZE are re
        "raw and x2-corrected values are both listed, hbm_bytes_per_frame uses the raw value", "kernels": {}}
 with open(os.path.join("profiles", tag + "_pmc.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg", "hbm_MB_per_launch_raw", "hbm_MB_per_launch_fetch_x2"])
+    w.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_per_batch", "WRITE_SIZE_KiB_per_batch", "hbm_MB_per_batch_raw", "hbm_MB_per_batch_fetch_x2"])
+    # batches in the profiled run = dispatches of the threshold kernel; a kernel launched twice per batch (the two walker
+    # passes) is summed per batch so that the numbers line up with bench.py's per-batch event intervals
+    nbatch = max(len(c.get("FETCH_SIZE", [])) for k, c in acc.items() if "threshold" in k)
     for k, c in acc.items():
-        fe = sum(c.get("FETCH_SIZE", [0])) / max(len(c.get("FETCH_SIZE", [1])), 1)
-        wr = sum(c.get("WRITE_SIZE", [0])) / max(len(c.get("WRITE_SIZE", [1])), 1)
+        fe = sum(c.get("FETCH_SIZE", [0])) / nbatch
+        wr = sum(c.get("WRITE_SIZE", [0])) / nbatch
         w.writerow([k, len(c.get("FETCH_SIZE", [])), round(fe, 1), round(wr, 1), round((fe + wr) * 1024 / 1e6, 2), round((2 * fe + wr) * 1024 / 1e6, 2)])
         short = k.split("(")[0].replace("void ", "").replace("ah::", "")
         short = short.split("<")[0]
