@@ -26,7 +26,7 @@ enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, ST
 static const char* kStageNames[STAGE_COUNT] = {"Threshold", "Rectangles", "Identify", "Subpixel", "Filtering"};
 // one event after every kernel of a batch; a ring of TSETS batches so that asynchronous steps can be averaged
 enum { K_THRESHOLD = 0, K_FILTER, K_WALKERS, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "filter_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
+static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "candidates_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
                                             "decode_kernel", "refine_lines_kernel", "refine_pixels_kernel", "finalize_kernel", "pose_kernel"};
 static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_IDENTIFY,
                                           STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_FILTERING};
@@ -409,9 +409,10 @@ static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectPara
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
     if (h->buf.seg_mode) {
         (void)hipMemsetAsync(h->buf.hash, 0xFF, (size_t)nframes * dp.nthr * (h->buf.hash_mask + 1) * sizeof(uint32_t), h->stream);
+        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
         launch_segments(h->stream, g, nframes * dp.nthr, dp, h->buf);
     } else {
-        launch_filter(h->stream, g, nframes * dp.nthr, h->buf);
+        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
         launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
     }
     launch_contour_quads(h->stream, g, nframes, dp, h->buf);
@@ -439,10 +440,11 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     MARK(1);
     if (b.seg_mode) {
         HIPCHK(h, hipMemsetAsync(b.hash, 0xFF, (size_t)nframes * dp.nthr * (b.hash_mask + 1) * sizeof(uint32_t), s));
+        launch_start_candidates(s, g, nframes * dp.nthr, b);
         MARK(2);
         launch_segments(s, g, nframes * dp.nthr, dp, b);
     } else {
-        launch_filter(s, g, nframes * dp.nthr, b);
+        launch_start_candidates(s, g, nframes * dp.nthr, b);
         MARK(2);
         launch_walkers(s, g, nframes * dp.nthr, dp, b);
     }

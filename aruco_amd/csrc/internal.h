@@ -3,7 +3,7 @@
 // HBM layout per handle (F = frames in the batch, T = threshold planes per frame, P = F*T planes):
 //   thres [P][H][W] u8   thresholded image (API-visible product, MarkerDetector::getThresholdedImage)
 //   tiles [P][H/8+1][W/8+1] u64 binary image cv::findContours works on, 8x8-pixel tiles (1-px frame cleared, zero pad row/col)
-//   raw   [P][capR] u32x2 local border-start candidates {hole, y<<16|x} from kernel 1
+//   raw   [P][capR] u32x2 segment mode only: waypoint cracks {start candidate, pos << 2 | code}
 //   trig  [P][capT] u32x2 candidates that pass the run rule
 //   cdesc list           borders that passed the size filter {plane, start, hole, n, key, pool offset}
 //   pool  short2 list    contour points
@@ -97,7 +97,7 @@ struct DetectParams {
 struct Buffers {
     uint8_t* thres;
     uint64_t* tiles;       // [P][tiles_y(H)][tiles_x(W)] binary image in 8x8-pixel tiles (bits_tiles.h)
-    uint2* raw;            // [P][cap_raw] local border-start candidates per plane
+    uint2* raw;            // [P][cap_raw] waypoint cracks per plane (segment mode)
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
@@ -131,7 +131,7 @@ struct Buffers {
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
-void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
+void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

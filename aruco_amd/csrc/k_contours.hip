@@ -6,13 +6,15 @@
 //
 // cv::findContours is a sequential raster scan that relabels pixels while it follows borders. The point sequence
 // of a border depends only on the binary image, its start pixel and whether it is a hole border, so the scan is
-// replaced by (a) local start candidates from kernel 1, thinned by the run rule (filter_kernel: the start of a border is
-// the first pixel of a horizontal run with nothing connected in the row above) and (b) one walker per candidate that follows the border
+// replaced by (a) local start candidates found on the tiled image, thinned by the run rule (candidates_kernel: the start of a
+// border is the first pixel of a horizontal run with nothing connected in the row above) and (b) one walker per candidate that follows the border
 // with OpenCV's step rule and drops itself as soon as it proves it is not the scan's start:
 //   outer border: a visited pixel precedes the start in raster order
 //   hole border : a 4-neighbour background pixel examined during the walk precedes the trigger pixel
 // or as soon as the border is longer than the size filter admits. Survivors are exactly the borders
 // detectRectangles keeps, with the same start and direction.
+#include <algorithm>
+
 #include "bits_tiles.h"
 #include "internal.h"
 
@@ -70,49 +72,166 @@ __device__ __forceinline__ bool run_rule_tiles(const uint64_t* __restrict__ tile
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 1b: run rule. A raw candidate survives only if it can be the first pixel of its component / hole in raster
-// order: outer - no set pixel 8-adjacent to its run of set pixels in the row above; hole - no clear pixel directly above
-// its run of clear pixels. Runs are followed for at most the two loaded words; longer ones keep the candidate.
+// Kernel 1b: border-start candidates from the tiled binary image. One lane per 8x8 tile evaluates the 3x3 start rule
+// of cv::findContours' raster scan for its 64 pixels with 64-bit logic on the tile and its W / N / NW / NE neighbours
+//   outer: pixel set,  W, NW, N, NE clear         hole: pixel clear, W and N set (pixel inside the 1-px frame)
+// and then the run rule for every hit: a candidate survives only if it can be the first pixel of its component / hole
+// in raster order (outer - no set pixel 8-adjacent to its run of set pixels in the row above; hole - no clear pixel
+// directly above its run of clear pixels). Survivors go to two lists per plane (outer starts in the first half of
+// trig[plane], hole starts in the second half) so that a walker wavefront follows only one kind of border.
+// Segment mode (k_segments.hip) instead gets the waypoint cracks of every tile: W / E cracks on grid rows, N / S cracks
+// on grid columns plus every start-candidate crack, as records {candidate flag, pos << 2 | code}.
 // ---------------------------------------------------------------------------------------------
-struct FilterArgs {
+struct CandArgs {
     const uint64_t* tiles;
     int tnx, tny;
-    const uint2* raw;
-    const uint32_t* raw_cnt;
+    int width, height;
     uint2* trig;
     uint32_t* trig_cnt;
+    uint2* raw;
+    uint32_t* raw_cnt;
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;
-    int height;
+    int seg_mode, grid_mask;
 };
 
-// Survivors go to two lists per plane (outer starts in the first half of trig[plane], hole starts in the second half)
-// so that a walker wavefront follows only one kind of border.
-__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
-    __shared__ uint2 s_keep[2][256];
-    __shared__ uint32_t s_n[2], s_base[2];
+constexpr int CAND_THREADS = 256;
+constexpr int CAND_STAGE = 512;   // staged records per list and round
+
+__global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
+    __shared__ uint2 s_keep[2][CAND_STAGE];
+    __shared__ uint2 s_long[CAND_STAGE];
+    __shared__ uint32_t s_n[2], s_base[2], s_nlong;
     const int plane = blockIdx.y;
-    const uint32_t nraw = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
-    const uint64_t* tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
-    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < nraw; i0 += gridDim.x * blockDim.x) {
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
+    const int ntx = a.tnx - 1, nty = a.tny - 1;          // real tiles (the pad column / row holds no pixel)
+    const int ntiles = ntx * nty;
+    const uint64_t COL0 = 0x0101010101010101ull, COL7 = 0x8080808080808080ull;
+    const uint32_t half = a.seg_mode ? a.cap_raw : a.cap_trig / 2;
+    uint2* const out = a.seg_mode ? a.raw + (size_t)plane * a.cap_raw : a.trig + (size_t)plane * a.cap_trig;
+    uint32_t* const out_cnt = (a.seg_mode ? a.raw_cnt : a.trig_cnt) + plane * TRIG_CNT_STRIDE;
+
+    // a record either enters the staging list of its kind or, when the round's list is full, goes straight to the plane's list
+    auto stage = [&](int kind, uint2 rec) {
+        const uint32_t ls = atomicAdd(&s_n[kind], 1u);
+        if (ls < CAND_STAGE) {
+            s_keep[kind][ls] = rec;
+        } else {
+            const uint32_t slot = atomicAdd(&out_cnt[kind], 1u);
+            if (slot < half)
+                out[(size_t)kind * half + slot] = rec;
+            else
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+        }
+    };
+
+    // a candidate whose run outlasts the pixels at hand waits for the 64-pixel test (or takes it at once if the list is full)
+    auto defer = [&](uint2 rec) {
+        const uint32_t ls = atomicAdd(&s_nlong, 1u);
+        if (ls < CAND_STAGE)
+            s_long[ls] = rec;
+        else if (run_rule_tiles(tiles, a.tnx, (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), (int)rec.x))
+            stage((int)rec.x, rec);
+    };
+
+    for (int i0 = blockIdx.x * CAND_THREADS; i0 < ntiles; i0 += gridDim.x * CAND_THREADS) {
         if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+        if (threadIdx.x == 2) s_nlong = 0;
         __syncthreads();
-        const uint32_t i = i0 + threadIdx.x;
-        if (i < nraw) {
-            const uint2 t = a.raw[(size_t)plane * a.cap_raw + i];
-            const int hole = (int)(t.x & 1u), x = (int)(t.y & 0xFFFFu), y = (int)(t.y >> 16);
-            const bool keep = run_rule_tiles(tiles, a.tnx, x, y, hole);
-            if (keep) s_keep[hole][atomicAdd(&s_n[hole], 1u)] = t;
+        const int i = i0 + threadIdx.x;
+        if (i < ntiles) {
+            const int ty = i / ntx, tx = i - ty * ntx;
+            const uint64_t* t = tiles + (size_t)ty * a.tnx + tx;
+            const uint64_t T = t[0];
+            const uint64_t L = tx > 0 ? t[-1] : 0ull;
+            const uint64_t U = ty > 0 ? t[-a.tnx] : 0ull, UL = (ty > 0 && tx > 0) ? t[-a.tnx - 1] : 0ull, UR = ty > 0 ? t[-a.tnx + 1] : 0ull;
+            const uint64_t Rt = t[1];
+            if (T | L | U) {     // a start needs a set pixel in the tile (outer) or set W and N neighbours (hole)
+                const uint64_t Wn = ((T << 1) & ~COL0) | ((L >> 7) & COL0);
+                const uint64_t N = (T << 8) | (U >> 56), NLt = (L << 8) | (UL >> 56), NRt = (Rt << 8) | (UR >> 56);
+                const uint64_t NW = ((N << 1) & ~COL0) | ((NLt >> 7) & COL0);
+                const uint64_t NE = ((N >> 1) & ~COL7) | ((NRt << 7) & COL7);
+                // pixels with x <= W-2 and y <= H-2 (x >= 1 and y >= 1 follow from the set W / N neighbours)
+                const int jmax = a.width - 2 - 8 * tx, imax = a.height - 2 - 8 * ty;
+                const uint64_t colm = (jmax >= 7 ? 0xFFull : ((1ull << (jmax + 1)) - 1ull)) * COL0;
+                const uint64_t rowm = imax >= 7 ? ~0ull : ((1ull << (8 * (imax + 1))) - 1ull);
+                const uint64_t outer = T & ~(Wn | NW | N | NE);
+                const uint64_t hole = ~T & Wn & N & colm & rowm;
+                const uint32_t base = ((uint32_t)(8 * ty) << 16) | (uint32_t)(8 * tx);
+                if (!a.seg_mode) {
+                    // run rule on the 16 - (x & 7) pixels at hand (this tile and its right neighbour, rows y and y-1); only a
+                    // run that leaves them undecided takes the 64-pixel test after the tile pass
+                    const uint64_t both = outer | hole;
+                    uint64_t m = both;
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int q = b >> 3, j = b & 7;
+                        const uint32_t kind = (uint32_t)(hole >> b) & 1u;
+                        const uint32_t mid = ((((uint32_t)(T >> (8 * q)) & 0xFFu) | (((uint32_t)(Rt >> (8 * q)) & 0xFFu) << 8)) >> j);
+                        const uint32_t up = ((((uint32_t)(N >> (8 * q)) & 0xFFu) | (((uint32_t)(NRt >> (8 * q)) & 0xFFu) << 8)) >> j);
+                        const int avail = 16 - j;
+                        const uint32_t pos = base + ((uint32_t)q << 16) + (uint32_t)j;
+                        // outer: run of set pixels from x, blockers = set pixels above columns x+2 .. x+L
+                        // hole : run of clear pixels from x, blockers = clear pixels above columns x+1 .. x+L-1
+                        const uint32_t runbits = (kind ? mid : ~mid) | (1u << avail);
+                        const int Lr = __builtin_ctz(runbits);                       // run length inside the window
+                        const int hi = kind ? min(Lr - 1, avail - 1) : min(Lr, avail - 1);
+                        const uint32_t span = ((2u << hi) - 1u) & (kind ? ~1u : ~3u);
+                        const bool blocked = ((kind ? ~up : up) & span) != 0;
+                        if (blocked) continue;
+                        if (Lr < avail)
+                            stage((int)kind, make_uint2(kind, pos));
+                        else
+                            defer(make_uint2(kind, pos));
+                    }
+                } else {
+                    // waypoint cracks (pixel p set, 4-neighbour clear). Record: y = (pos(p) << 2) | code (E=0,N=1,W=2,S=3),
+                    // x = 1 if the crack is a border-start candidate.
+                    uint64_t rsel = 0, csel = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (((8 * ty + q) & a.grid_mask) == 0) rsel |= 0xFFull << (8 * q);
+                        if (((8 * tx + q) & a.grid_mask) == 0) csel |= COL0 << q;
+                    }
+                    const uint64_t crW = T & ~Wn & (rsel | outer);          // W crack of the set pixel
+                    const uint64_t crE = ~T & Wn & (rsel | hole);           // E crack of p, seen from the clear pixel z = p + 1
+                    const uint64_t crN = T & ~N & csel;                     // N crack of the set pixel
+                    const uint64_t crS = N & ~T & csel;                     // S crack of the pixel above, seen from the clear pixel
+                    for (int kind = 0; kind < 4; kind++) {
+                        uint64_t m = kind == 0 ? crW : kind == 1 ? crE : kind == 2 ? crN : crS;
+                        while (m) {
+                            const int b = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t z = base + ((uint32_t)(b >> 3) << 16) + (uint32_t)(b & 7);
+                            uint32_t pos, code, cand = 0;
+                            if (kind == 0) pos = z, code = 2u, cand = (uint32_t)(outer >> b) & 1u;
+                            else if (kind == 1) pos = z - 1u, code = 0u, cand = (uint32_t)(hole >> b) & 1u;
+                            else if (kind == 2) pos = z, code = 1u;
+                            else pos = z - 65536u, code = 3u;
+                            stage(0, make_uint2(cand, (pos << 2) | code));
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + threadIdx.x], s_n[threadIdx.x]);
+        {
+            const uint32_t nlong = min(s_nlong, (uint32_t)CAND_STAGE);
+            for (uint32_t j = threadIdx.x; j < nlong; j += CAND_THREADS) {
+                const uint2 rec = s_long[j];
+                if (run_rule_tiles(tiles, a.tnx, (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), (int)rec.x)) stage((int)rec.x, rec);
+            }
+        }
         __syncthreads();
-        const uint32_t half = a.cap_trig / 2;
+        if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&out_cnt[threadIdx.x], min(s_n[threadIdx.x], (uint32_t)CAND_STAGE));
+        __syncthreads();
         for (int kind = 0; kind < 2; kind++) {
-            if (threadIdx.x < s_n[kind]) {
-                const uint32_t slot = s_base[kind] + threadIdx.x;
+            const uint32_t n = min(s_n[kind], (uint32_t)CAND_STAGE);
+            for (uint32_t j = threadIdx.x; j < n; j += CAND_THREADS) {
+                const uint32_t slot = s_base[kind] + j;
                 if (slot < half)
-                    a.trig[(size_t)plane * a.cap_trig + kind * half + slot] = s_keep[kind][threadIdx.x];
+                    out[(size_t)kind * half + slot] = s_keep[kind][j];
                 else
                     atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
             }
@@ -121,12 +240,16 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
     }
 }
 
-void launch_filter(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
-    FilterArgs a;
+void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
+    CandArgs a;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
-    a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters;
-    a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig, a.height = g.height;
-    hipLaunchKernelGGL(filter_kernel, dim3(8, nplanes), dim3(256), 0, s, a);
+    a.width = g.width, a.height = g.height;
+    a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters;
+    a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig;
+    a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
+    const int ntiles = (a.tnx - 1) * (a.tny - 1);
+    const int chunks = std::max(1, std::min(16, (ntiles + 4 * CAND_THREADS - 1) / (4 * CAND_THREADS)));
+    hipLaunchKernelGGL(candidates_kernel, dim3(chunks, nplanes), dim3(CAND_THREADS), 0, s, a);
 }
 
 constexpr int CK = 16;   // border steps between two checkpoints

@@ -6,7 +6,7 @@
 // CRACK (set pixel p, clear 4-neighbour in direction e) is examined in exactly one visit of exactly one border, and that
 // visit's state is a function of the 3x3 neighbourhood alone: s = first set neighbour clockwise from e.
 //
-//  1. Kernel 1 emits WAYPOINTS: the cracks on a sparse grid (W/E cracks on rows y % S == 0, N/S cracks on columns
+//  1. candidates_kernel (k_contours.hip) emits WAYPOINTS: the cracks on a sparse grid (W/E cracks on rows y % S == 0, N/S cracks on columns
 //     x % S == 0) plus every crack that can start a border (the 3x3 start rule). Every border that spans more than S rows
 //     or columns crosses a grid line and therefore carries waypoints every few pixels.
 //  2. segment_kernel (one lane per waypoint): follow the border from the waypoint's visit until the next waypoint crack is
@@ -73,7 +73,7 @@ constexpr int CYC_CHUNKS = 32;   // 64-thread workgroups per plane in the lap ke
 
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask) { return (key * 2654435761u >> 7) & mask; }
 
-// run rule for a start-candidate crack (same test as filter_kernel in k_contours.hip)
+// run rule for a start-candidate crack (same test as candidates_kernel in k_contours.hip)
 __device__ __forceinline__ bool run_rule(const uint64_t* __restrict__ tiles, int tnx, uint32_t pos, int e) {
     const int hole = e == 0;
     const uint32_t zpos = pos + (hole ? 1u : 0u);            // outer: the pixel itself; hole: the clear pixel right of p
