@@ -58,7 +58,7 @@ assert MARKER_DTYPE.itemsize == 96 and C.sizeof(Marker) == 96
 SYMBOLS = [
     "arucohip_version", "arucohip_default_params", "arucohip_default_limits", "arucohip_create", "arucohip_create_ex",
     "arucohip_destroy", "arucohip_set_params", "arucohip_get_params", "arucohip_last_error_string", "arucohip_set_stream",
-    "arucohip_get_stream", "arucohip_synchronize", "arucohip_detect", "arucohip_detect_batch", "arucohip_batch_status",
+    "arucohip_get_stream", "arucohip_synchronize", "arucohip_detect", "arucohip_detect_batch", "arucohip_batch_status", "arucohip_batch_chunks",
     "arucohip_get_thresholded", "arucohip_get_candidates", "arucohip_threshold", "arucohip_detect_rectangles",
     "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
@@ -102,6 +102,7 @@ def load():
     L.arucohip_detect.argtypes = [vp, vp, i, i, sz, vp, vp, i, f, i, vp, i, vp]
     L.arucohip_detect_batch.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i]
     L.arucohip_batch_status.argtypes = [vp]
+    L.arucohip_batch_chunks.argtypes = [vp, C.POINTER(C.c_int)]
     L.arucohip_get_thresholded.argtypes = [vp, i, vp]
     L.arucohip_get_candidates.argtypes = [vp, i, vp, i, vp]
     L.arucohip_threshold.argtypes = [vp, i, vp, i, i, sz, C.c_double, C.c_double, vp]
@@ -230,6 +231,12 @@ class Handle:
 
     def batch_status(self):
         return self._chk(self.L.arucohip_batch_status(self.h))
+
+    def batch_chunks(self):
+        """(chunks, frames per chunk) of the last batch: every kernel launch covers one chunk."""
+        per = C.c_int(0)
+        n = self.L.arucohip_batch_chunks(self.h, C.byref(per))
+        return n, per.value
 
     def thresholded(self, frame=0, shape=None):
         out = np.empty(shape, np.uint8)

@@ -62,8 +62,29 @@ struct arucohip_handle {
     hipEvent_t ev[TSETS][K_COUNT + 1] = {};
     int tsets = 0;                       // batches recorded since the last reset
     float kernel_ms[K_COUNT] = {};       // averages over the recorded batches
+    // Sub-batch pipelining: a batch larger than cap_frames is cut into up to nsub chunks; chunk 0 runs on this handle and
+    // the caller's stream, chunk i on kids[i-1] and its own stream, so the latency-bound kernels of one chunk (border
+    // following, Otsu) overlap the bandwidth-bound ones of another and host frames are copied while earlier chunks compute.
+    int nsub = 1, cap_frames = 1;        // workers, frames each worker's buffers hold
+    bool is_child = false;
+    std::vector<arucohip_handle*> kids;
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+    hipEvent_t ev_thr = nullptr;         // this worker's threshold kernel has finished (staggers the chunks, see detect_batch)
+    hipEvent_t wait_thr = nullptr;       // set by detect_batch: event the next threshold kernel waits for
+    int last_chunks = 1, last_per = 0;   // chunks and frames per chunk of the last batch
     std::string err;
 };
+
+// worker that holds frame `frame` of the last batch (and the frame's index inside that worker)
+static arucohip_handle* route(arucohip_handle* h, int frame, int* local) {
+    if (h->last_chunks <= 1 || h->last_per <= 0) {
+        *local = frame;
+        return h;
+    }
+    const int c = std::min(frame / h->last_per, h->last_chunks - 1);
+    *local = frame - c * h->last_per;
+    return c == 0 ? h : h->kids[c - 1];
+}
 
 #define HIPCHK(h, expr)                                                                         \
     do {                                                                                        \
@@ -125,8 +146,15 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
     return ARUCOHIP_OK;
 }
 
+extern "C" void arucohip_destroy(arucohip_handle* h);
 static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
+    for (auto* k : h->kids) arucohip_destroy(k);
+    h->kids.clear();
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_thr) hipEventDestroy(h->ev_thr);
+    for (auto& e : h->ev_join)
+        if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.trig2), hipFree(h->buf.trig2_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
@@ -138,6 +166,8 @@ static void free_all(arucohip_handle* h) {
             if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
 }
+
+static thread_local bool g_creating_child = false;
 
 int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* lim, arucohip_handle** out) {
     if (!out || !lim) return ARUCOHIP_E_INVALID;
@@ -167,7 +197,17 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e);
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
     h->stream = h->own_stream;
-    const size_t F = lim->max_batch, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
+    {
+        // workers: at least ~128 Mpx of frames per chunk, at most 4 (ARUCOHIP_STREAMS overrides, 1 disables)
+        const double mpx = (double)lim->max_batch * lim->max_width * lim->max_height / (128.0 * 1024 * 1024);
+        int ns = (int)std::min(4.0, std::max(1.0, std::floor(mpx)));
+        if (const char* es = getenv("ARUCOHIP_STREAMS")) ns = std::min(8, std::max(1, atoi(es)));
+        if (g_creating_child) ns = 1;
+        h->is_child = g_creating_child;
+        h->nsub = std::min(ns, lim->max_batch);
+        h->cap_frames = (lim->max_batch + h->nsub - 1) / h->nsub;
+    }
+    const size_t F = h->cap_frames, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
@@ -226,6 +266,25 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     for (auto& set : h->ev)
         for (auto& ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&h->ev_thr, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    if (h->nsub > 1) {
+        if ((e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e);
+        for (int i = 0; i < h->nsub - 1; i++) {
+            if ((e = hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming)) != hipSuccess) return bail(e);
+            arucohip_limits_t kl = *lim;
+            kl.max_batch = h->cap_frames;
+            arucohip_handle* kid = nullptr;
+            g_creating_child = true;
+            int krc = arucohip_create_ex(&h->params, device, &kl, &kid);
+            g_creating_child = false;
+            if (krc != ARUCOHIP_OK) {
+                free_all(h);
+                delete h;
+                return krc;
+            }
+            h->kids.push_back(kid);
+        }
+    }
     *out = h;
     return ARUCOHIP_OK;
 }
@@ -250,6 +309,7 @@ int arucohip_set_params(arucohip_handle* h, const arucohip_params_t* p) {
     if (2 * p->thres_param1_range + 1 > h->lim.max_thres_planes)
         return fail(h, ARUCOHIP_E_INVALID, "threshold range exceeds the planes this handle was created with");
     h->params = *p;
+    for (auto* k : h->kids) k->params = *p;
     return ARUCOHIP_OK;
 }
 
@@ -279,21 +339,30 @@ int arucohip_enable_timing(arucohip_handle* h, int on) {
     if (!h) return ARUCOHIP_E_INVALID;
     h->timing = on != 0;
     h->tsets = 0;
+    for (auto* k : h->kids) k->timing = h->timing, k->tsets = 0;
     return ARUCOHIP_OK;
 }
 // synchronises the stream and averages the per-kernel event intervals of the batches since enable/reset
+// (with sub-batch pipelining: the average over the launches of all workers, each launch covering one chunk)
 static void collect_times(arucohip_handle* h) {
     for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] = 0;
-    int n = std::min(h->tsets, TSETS);
-    if (n <= 0) return;
     hipSetDevice(h->device);
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return;
-    for (int s = 0; s < n; s++)
-        for (int k = 0; k < K_COUNT; k++) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, h->ev[s][k], h->ev[s][k + 1]) == hipSuccess) h->kernel_ms[k] += ms;
-        }
-    for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] /= n;
+    int total = 0;
+    auto add = [&](arucohip_handle* w) {
+        int n = std::min(w->tsets, TSETS);
+        if (n <= 0) return;
+        if (hipStreamSynchronize(w->stream) != hipSuccess) return;
+        for (int s = 0; s < n; s++)
+            for (int k = 0; k < K_COUNT; k++) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, w->ev[s][k], w->ev[s][k + 1]) == hipSuccess) h->kernel_ms[k] += ms;
+            }
+        total += n;
+    };
+    add(h);
+    for (auto* k : h->kids) add(k);
+    if (total > 0)
+        for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] /= total;
 }
 const char* arucohip_stage_name(int i) { return (i >= 0 && i < STAGE_COUNT) ? kStageNames[i] : ""; }
 int arucohip_stage_times(arucohip_handle* h, float* ms, int cap) {
@@ -436,7 +505,9 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
     MARK(0);
+    if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));
     launch_threshold(s, gray_dev, g, nframes, dp, b);
+    if (h->ev_thr) HIPCHK(h, hipEventRecord(h->ev_thr, s));
     MARK(1);
     if (b.seg_mode) {
         HIPCHK(h, hipMemsetAsync(b.hash, 0xFF, (size_t)nframes * dp.nthr * (b.hash_mask + 1) * sizeof(uint32_t), s));
@@ -504,6 +575,63 @@ static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t 
 
 extern "C" {
 
+// enqueue one chunk on worker w (its buffers, its stream); results go to device memory or to w's pinned staging
+static int chunk_enqueue(arucohip_handle* w, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                         int frames_on_device, const DetectParams& dp, const CamModel& cam, arucohip_marker_t* out, int cap, int32_t* n_out,
+                         int out_on_device) {
+    int rc;
+    const uint8_t* gray_dev;
+    FrameGeom g;
+    if ((rc = stage_frames(w, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, &gray_dev, &g))) return rc;
+    if ((rc = detect_core(w, gray_dev, g, nframes, dp, cam))) return rc;
+    const Buffers& b = w->buf;
+    const int ncopy = std::min(cap, b.cap_markers);
+    if (out_on_device) {
+        if (ncopy > 0)
+            HIPCHK(w, hipMemcpy2DAsync(out, (size_t)cap * sizeof(arucohip_marker_t), b.markers, (size_t)b.cap_markers * sizeof(arucohip_marker_t),
+                                       (size_t)ncopy * sizeof(arucohip_marker_t), nframes, hipMemcpyDeviceToDevice, w->stream));
+        HIPCHK(w, hipMemcpyAsync(n_out, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToDevice, w->stream));
+        return ARUCOHIP_OK;
+    }
+    HIPCHK(w, hipMemcpyAsync(w->h_markers, b.markers, (size_t)nframes * b.cap_markers * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->h_n, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+    return ARUCOHIP_OK;
+}
+
+// after the worker's stream has drained: copy the chunk's markers from the pinned staging to the caller's arrays
+static int chunk_collect_host(arucohip_handle* h, arucohip_handle* w, int nframes, arucohip_marker_t* out, int cap, int32_t* n_out) {
+    int ret = check_status(h, w->h_counters[CNT_STATUS] & ~(uint32_t)ST_MARKER_OVERFLOW);
+    const Buffers& b = w->buf;
+    for (int f = 0; f < nframes; f++) {
+        int n = w->h_n[f];
+        n_out[f] = n;
+        if (n > cap) {
+            if (ret == ARUCOHIP_OK) ret = fail(h, ARUCOHIP_E_CAPACITY, "marker output array too small");
+            n = cap;
+        }
+        n = std::min(n, b.cap_markers);
+        if (n > 0) std::memcpy(out + (size_t)f * cap, w->h_markers + (size_t)f * b.cap_markers, (size_t)n * sizeof(arucohip_marker_t));
+    }
+    return ret;
+}
+
+// fork: the workers' streams wait for what the caller's stream has queued so far
+static int fork_workers(arucohip_handle* h, int chunks) {
+    if (chunks <= 1) return ARUCOHIP_OK;
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    for (int c = 1; c < chunks; c++) HIPCHK(h, hipStreamWaitEvent(h->kids[c - 1]->stream, h->ev_fork, 0));
+    return ARUCOHIP_OK;
+}
+// join: the caller's stream waits for the workers
+static int join_workers(arucohip_handle* h, int chunks) {
+    for (int c = 1; c < chunks; c++) {
+        HIPCHK(h, hipEventRecord(h->ev_join[c - 1], h->kids[c - 1]->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[c - 1], 0));
+    }
+    return ARUCOHIP_OK;
+}
+
 int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
                           int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
                           arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
@@ -515,33 +643,36 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
     CamModel cam;
     if ((rc = make_detect_params(h, W, H, &dp))) return rc;
     if ((rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam))) return rc;
-    const uint8_t* gray_dev;
-    FrameGeom g;
-    if ((rc = stage_frames(h, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, &gray_dev, &g))) return rc;
-    if ((rc = detect_core(h, gray_dev, g, nframes, dp, cam))) return rc;
-    const Buffers& b = h->buf;
-    const int ncopy = std::min(cap, b.cap_markers);
-    if (out_on_device) {
-        if (ncopy > 0)
-            HIPCHK(h, hipMemcpy2DAsync(out, (size_t)cap * sizeof(arucohip_marker_t), b.markers, (size_t)b.cap_markers * sizeof(arucohip_marker_t),
-                                       (size_t)ncopy * sizeof(arucohip_marker_t), nframes, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(n_out, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-        return ARUCOHIP_OK;
-    }
-    HIPCHK(h, hipMemcpyAsync(h->h_markers, b.markers, (size_t)nframes * b.cap_markers * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_n, b.nmarkers, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    int ret = check_status(h, h->h_counters[CNT_STATUS] & ~(uint32_t)ST_MARKER_OVERFLOW);
-    for (int f = 0; f < nframes; f++) {
-        int n = h->h_n[f];
-        n_out[f] = n;
-        if (n > cap) {
-            if (ret == ARUCOHIP_OK) ret = fail(h, ARUCOHIP_E_CAPACITY, "marker output array too small");
-            n = cap;
+    // chunks of equal size, as few as the workers' buffers allow but one per worker when the batch is large enough to share
+    int chunks = (nframes + h->cap_frames - 1) / h->cap_frames;
+    if (h->nsub > 1 && (size_t)nframes * W * H >= (size_t)h->nsub * 32 * 1024 * 1024) chunks = std::max(chunks, std::min(h->nsub, nframes));
+    const int per = (nframes + chunks - 1) / chunks;
+    chunks = (nframes + per - 1) / per;
+    h->last_chunks = chunks, h->last_per = per;
+    if ((rc = fork_workers(h, chunks))) return rc;
+    for (int c = 0; c < chunks; c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        const int off = c * per, cnt = std::min(per, nframes - off);
+        // stagger: the bandwidth-bound threshold kernels of the chunks run one after the other, so that chunk c's
+        // threshold overlaps the latency-bound border following / decoding of chunk c-1 instead of its threshold
+        static const bool chain = !(getenv("ARUCOHIP_CHAIN") && atoi(getenv("ARUCOHIP_CHAIN")) == 0);
+        w->wait_thr = (chain && c > 0) ? (c == 1 ? h : h->kids[c - 2])->ev_thr : nullptr;
+        rc = chunk_enqueue(w, frames + (size_t)off * frame_stride, cnt, W, H, row_stride, frame_stride, frames_on_device, dp, cam,
+                           out ? out + (size_t)off * cap : nullptr, cap, n_out + off, out_on_device);
+        if (rc) {
+            if (w != h) h->err = w->err;
+            return rc;
         }
-        n = std::min(n, b.cap_markers);
-        if (n > 0) std::memcpy(out + (size_t)f * cap, h->h_markers + (size_t)f * b.cap_markers, (size_t)n * sizeof(arucohip_marker_t));
+    }
+    if ((rc = join_workers(h, chunks))) return rc;
+    if (out_on_device) return ARUCOHIP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int ret = ARUCOHIP_OK;
+    for (int c = 0; c < chunks; c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        const int off = c * per, cnt = std::min(per, nframes - off);
+        int r = chunk_collect_host(h, w, cnt, out + (size_t)off * cap, cap, n_out + off);
+        if (ret == ARUCOHIP_OK) ret = r;
     }
     return ret;
 }
@@ -549,9 +680,21 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
 int arucohip_batch_status(arucohip_handle* h) {
     if (!h) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    uint32_t st = 0;
+    for (int c = 0; c < std::max(h->last_chunks, 1); c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        HIPCHK(h, hipMemcpyAsync(w->h_counters, w->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(h, hipStreamSynchronize(w->stream));
+        st |= w->h_counters[CNT_STATUS];
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_status(h, h->h_counters[CNT_STATUS]);
+    return check_status(h, st);
+}
+
+int arucohip_batch_chunks(arucohip_handle* h, int* frames_per_chunk) {
+    if (!h) return 0;
+    if (frames_per_chunk) *frames_per_chunk = h->last_chunks > 1 ? h->last_per : h->last_frames;
+    return std::max(h->last_chunks, 1);
 }
 
 int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t row_stride, const float* K, const float* dist, int ndist,
@@ -562,8 +705,10 @@ int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int W, int H, size_
     return rc;
 }
 
-int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst) {
-    if (!h || !dst || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+int arucohip_get_thresholded(arucohip_handle* h0, int frame, uint8_t* dst) {
+    if (!h0 || !dst || frame < 0) return ARUCOHIP_E_INVALID;
+    arucohip_handle* h = route(h0, frame, &frame);
+    if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     size_t px = (size_t)h->last_w * h->last_h;
     int plane = frame * h->last_nthr + h->last_nthr / 2;   // thres = thres_images[n_param1 / 2]
@@ -572,8 +717,10 @@ int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst) {
     return ARUCOHIP_OK;
 }
 
-static int fetch_cands(arucohip_handle* h, int frame, std::vector<Cand>* v) {
-    if (!h || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+static int fetch_cands(arucohip_handle* h0, int frame, std::vector<Cand>* v) {
+    if (!h0 || frame < 0) return ARUCOHIP_E_INVALID;
+    arucohip_handle* h = route(h0, frame, &frame);
+    if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     int32_t n = 0;
     HIPCHK(h, hipMemcpyAsync(&n, h->buf.ncands + frame, sizeof(n), hipMemcpyDeviceToHost, h->stream));
@@ -619,8 +766,11 @@ int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int3
 }
 
 // contours of one frame in reference (RETR_LIST) order: planes ascending, raster key descending
-static int fetch_contours(arucohip_handle* h, int frame, std::vector<ContourDesc>* out) {
-    if (!h || frame < 0 || frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+static int fetch_contours(arucohip_handle* h0, int frame, std::vector<ContourDesc>* out, arucohip_handle** owner = nullptr) {
+    if (!h0 || frame < 0) return ARUCOHIP_E_INVALID;
+    arucohip_handle* h = route(h0, frame, &frame);
+    if (owner) *owner = h;
+    if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     uint32_t cnt[CNT_FIXED];
     HIPCHK(h, hipMemcpyAsync(cnt, h->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
@@ -649,9 +799,10 @@ int arucohip_debug_num_contours(arucohip_handle* h, int frame, int* n) {
     return ARUCOHIP_OK;
 }
 
-int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hole, int* sx, int* sy, int16_t* xy, int cap_points, int* n_points) {
+int arucohip_debug_contour(arucohip_handle* h0, int frame, int index, int* is_hole, int* sx, int* sy, int16_t* xy, int cap_points, int* n_points) {
     std::vector<ContourDesc> v;
-    int rc = fetch_contours(h, frame, &v);
+    arucohip_handle* h = h0;
+    int rc = fetch_contours(h0, frame, &v, &h);
     if (rc) return rc;
     if (index < 0 || index >= (int)v.size()) return ARUCOHIP_E_INVALID;
     const ContourDesc& c = v[index];
@@ -671,19 +822,26 @@ int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hol
 int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
     if (!h || !out8) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(out8, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    int planes = std::max(h->last_frames * h->last_nthr, 1);
-    std::vector<uint32_t> tc((size_t)planes * TRIG_CNT_STRIDE);
-    HIPCHK(h, hipMemcpyAsync(tc.data(), h->buf.trig_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    uint64_t tot = 0;
-    for (int p = 0; p < planes; p++) tot += tc[(size_t)p * TRIG_CNT_STRIDE];
-    out8[0] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFu);
-    HIPCHK(h, hipMemcpyAsync(tc.data(), h->buf.raw_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    tot = 0;
-    for (int p = 0; p < planes; p++) tot += tc[(size_t)p * TRIG_CNT_STRIDE];
-    out8[4] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFu);
+    uint64_t acc[CNT_FIXED] = {};
+    uint64_t ntrig = 0, nraw = 0;
+    for (int c = 0; c < std::max(h->last_chunks, 1); c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        uint32_t cnt[CNT_FIXED];
+        HIPCHK(h, hipMemcpyAsync(cnt, w->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, w->stream));
+        int planes = std::max(w->last_frames * w->last_nthr, 1);
+        std::vector<uint32_t> tc((size_t)planes * TRIG_CNT_STRIDE), rc_((size_t)planes * TRIG_CNT_STRIDE);
+        HIPCHK(h, hipMemcpyAsync(tc.data(), w->buf.trig_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(h, hipMemcpyAsync(rc_.data(), w->buf.raw_cnt, rc_.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(h, hipStreamSynchronize(w->stream));
+        for (int i = 0; i < CNT_FIXED; i++) acc[i] = (i == CNT_STATUS) ? (acc[i] | cnt[i]) : acc[i] + cnt[i];
+        for (int p = 0; p < planes; p++) {
+            ntrig += tc[(size_t)p * TRIG_CNT_STRIDE] + tc[(size_t)p * TRIG_CNT_STRIDE + 1];
+            nraw += rc_[(size_t)p * TRIG_CNT_STRIDE];
+        }
+    }
+    for (int i = 0; i < CNT_FIXED; i++) out8[i] = (uint32_t)std::min<uint64_t>(acc[i], 0xFFFFFFFFu);
+    out8[0] = (uint32_t)std::min<uint64_t>(ntrig, 0xFFFFFFFFu);   // start candidates after the run rule (all planes)
+    out8[4] = (uint32_t)std::min<uint64_t>(nraw, 0xFFFFFFFFu);    // waypoint records (segment mode)
     return ARUCOHIP_OK;
 }
 
@@ -717,7 +875,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1;
+    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1, h->last_chunks = 1;
     return ARUCOHIP_OK;
 }
 
@@ -744,7 +902,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     launch_binary_planes(h->stream, dev, g, 1, h->buf);
     run_rectangles(h, g, 1, dp);
     HIPCHK(h, hipGetLastError());
-    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1;
+    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = 1, h->last_chunks = 1;
     std::vector<Cand> v;
     if ((rc = fetch_cands(h, 0, &v))) return rc;
     HIPCHK(h, hipMemcpy(h->h_counters, h->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -776,7 +934,10 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
                                 const float* dist, int ndist, float marker_size, float repj_err_thres, int y_perp, arucohip_board_t* out, float* prob) {
     if (!h || !out || !prob) return ARUCOHIP_E_INVALID;
     if (nboard <= 0 || !ids || !obj) return fail(h, ARUCOHIP_E_BOARD_CONFIG, "invalid BoardConfig that is empty");
-    if (nframes < 1 || nframes > h->last_frames) return fail(h, ARUCOHIP_E_INVALID, "nframes exceeds the last batch");
+    const int chunks = std::max(h->last_chunks, 1), per = chunks > 1 ? h->last_per : h->last_frames;
+    int have = 0;
+    for (int c = 0; c < chunks; c++) have += (c == 0 ? h : h->kids[c - 1])->last_frames;
+    if (nframes < 1 || nframes > have) return fail(h, ARUCOHIP_E_INVALID, "nframes exceeds the last batch");
     if (nboard * 12 > 8192) return fail(h, ARUCOHIP_E_CAPACITY, "board with too many markers");
     HIPCHK(h, hipSetDevice(h->device));
     float zeros[4] = {0, 0, 0, 0};
@@ -784,18 +945,25 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
     CamModel cam;
     int rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam);
     if (rc) return rc;
-    if (!h->d_board) {
-        HIPCHK(h, hipMalloc((void**)&h->d_board, (size_t)h->lim.max_batch * (sizeof(arucohip_board_t) + sizeof(float)) + 8192 * sizeof(int32_t)));
+    // every worker solves the boards of the frames it detected, on its own stream
+    if ((rc = fork_workers(h, chunks))) return rc;
+    for (int c = 0; c < chunks; c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        const int off = c * per, cnt = std::min(per, nframes - off);
+        if (cnt <= 0) break;
+        if (!w->d_board)
+            HIPCHK(h, hipMalloc((void**)&w->d_board, (size_t)w->cap_frames * (sizeof(arucohip_board_t) + sizeof(float)) + 8192 * sizeof(int32_t)));
+        arucohip_board_t* d_out = (arucohip_board_t*)w->d_board;
+        float* d_prob = (float*)(d_out + w->cap_frames);
+        int32_t* d_ids = (int32_t*)(d_prob + w->cap_frames);
+        HIPCHK(h, hipMemcpyAsync(d_ids, ids, (size_t)nboard * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+        HIPCHK(h, hipMemcpyAsync(w->d_small_f, obj, (size_t)nboard * 12 * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        launch_board_pose(w->stream, cnt, w->buf, d_ids, w->d_small_f, nboard, info_type, marker_size, repj_err_thres, cam, d_out, d_prob);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out + off, d_out, (size_t)cnt * sizeof(arucohip_board_t), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(h, hipMemcpyAsync(prob + off, d_prob, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     }
-    arucohip_board_t* d_out = (arucohip_board_t*)h->d_board;
-    float* d_prob = (float*)(d_out + h->lim.max_batch);
-    int32_t* d_ids = (int32_t*)(d_prob + h->lim.max_batch);
-    HIPCHK(h, hipMemcpyAsync(d_ids, ids, (size_t)nboard * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_small_f, obj, (size_t)nboard * 12 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    launch_board_pose(h->stream, nframes, h->buf, d_ids, h->d_small_f, nboard, info_type, marker_size, repj_err_thres, cam, d_out, d_prob);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)nframes * sizeof(arucohip_board_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(prob, d_prob, (size_t)nframes * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = join_workers(h, chunks))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ARUCOHIP_OK;
 }
@@ -805,7 +973,7 @@ int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers
     if (!h || !markers || n < 0 || !K) return ARUCOHIP_E_INVALID;
     if (!(marker_size > 0)) return fail(h, ARUCOHIP_E_INVALID, "marker size must be positive");   // marker.cpp:114
     if (n == 0) return ARUCOHIP_OK;
-    if ((size_t)n > (size_t)h->lim.max_batch * h->buf.cap_markers) return fail(h, ARUCOHIP_E_CAPACITY, "too many markers for this handle");
+    if ((size_t)n > (size_t)h->cap_frames * h->buf.cap_markers) return fail(h, ARUCOHIP_E_CAPACITY, "too many markers for this handle");
     HIPCHK(h, hipSetDevice(h->device));
     CamModel cam;
     int rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam);

@@ -172,7 +172,8 @@ def main():
     elapsed = time.perf_counter() - t0
     handle.batch_status()                       # raises on any device-side list overflow
     elapsed = adist.max_over_ranks(elapsed, dev)
-    ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch stream over the timed steps
+    ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams over the timed steps
+    chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
     handle.enable_timing(False)
 
     # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
@@ -197,14 +198,14 @@ def main():
         fps = total_frames / elapsed
         dom = max(ktimes, key=lambda k: ktimes[k])
         dom_ms = ktimes[dom]
-        achieved = ALG_BYTES_PER_FRAME * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if dom in tj.get("kernels", {}):
-                    traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * B
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * per_launch
             except Exception:
                 traffic = None
         res = {
@@ -222,8 +223,9 @@ def main():
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * B, "avg_launch_ms": round(dom_ms, 4)},
-            "kernel_ms_per_step": {k: round(v, 4) for k, v in ktimes.items()},
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * per_launch, "frames_per_launch": per_launch,
+                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4)},
+            "kernel_ms_per_launch": {k: round(v, 4) for k, v in ktimes.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             nsample = min(32, args.frames)
