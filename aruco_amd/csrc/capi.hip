@@ -123,7 +123,7 @@ void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height
     l->max_thres_planes = 1;
     long px = (long)max_width * max_height;
     l->triggers_per_frame = (int)std::min<long>(std::max<long>(px / 16, 16384), 1 << 20);
-    l->contours_per_frame = 1024;
+    l->contours_per_frame = (int)std::min<long>(std::max<long>(px / 256, 1024), 16384);   // per threshold plane
     l->points_per_frame = (int)std::min<long>(std::max<long>(px / 8, 65536), 1 << 21);
     l->candidates_per_frame = 256;
     l->markers_per_frame = 128;
@@ -198,9 +198,10 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
     h->stream = h->own_stream;
     {
-        // workers: at least ~128 Mpx of frames per chunk, at most 4 (ARUCOHIP_STREAMS overrides, 1 disables)
+        // workers: at least ~128 Mpx of frames per chunk, at most 2 (ARUCOHIP_STREAMS overrides, 1 disables). Measured on
+        // three MI355X boxes at 1024 1080p frames: 1 stream 155-158 k fps, 2 streams 174-179 k, 4 streams 145 k.
         const double mpx = (double)lim->max_batch * lim->max_width * lim->max_height / (128.0 * 1024 * 1024);
-        int ns = (int)std::min(4.0, std::max(1.0, std::floor(mpx)));
+        int ns = (int)std::min(2.0, std::max(1.0, std::floor(mpx)));
         if (const char* es = getenv("ARUCOHIP_STREAMS")) ns = std::min(8, std::max(1, atoi(es)));
         if (g_creating_child) ns = 1;
         h->is_child = g_creating_child;
@@ -211,8 +212,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     Buffers& b = h->buf;
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
-    b.cap_cdesc = (uint32_t)std::min<size_t>(P * lim->contours_per_frame, 0xFFFFFFF0u);
-    b.cap_pool = (uint32_t)std::min<size_t>(P * lim->points_per_frame, 0xFFFFFFF0u);
+    b.cap_cdesc = (uint32_t)lim->contours_per_frame;   // per plane
+    b.cap_pool = (uint32_t)lim->points_per_frame;       // per plane
     b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);
     b.cap_cands = lim->candidates_per_frame;
     b.cap_markers = lim->markers_per_frame;
@@ -242,8 +243,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig2, P * (size_t)b.cap_trig * sizeof(uint2));
     ALLOC(b.trig2_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
-    ALLOC(b.cdesc, (size_t)b.cap_cdesc * sizeof(ContourDesc));
-    ALLOC(b.pool, (size_t)b.cap_pool * sizeof(short2));
+    ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
+    ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
     ALLOC(b.cands, F * b.cap_cands * sizeof(Cand));
     ALLOC(b.ncands, F * sizeof(int32_t));
@@ -653,9 +654,10 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
     for (int c = 0; c < chunks; c++) {
         arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
         const int off = c * per, cnt = std::min(per, nframes - off);
-        // stagger: the bandwidth-bound threshold kernels of the chunks run one after the other, so that chunk c's
-        // threshold overlaps the latency-bound border following / decoding of chunk c-1 instead of its threshold
-        static const bool chain = !(getenv("ARUCOHIP_CHAIN") && atoi(getenv("ARUCOHIP_CHAIN")) == 0);
+        // optional stagger (ARUCOHIP_CHAIN=1): the bandwidth-bound threshold kernels of the chunks run one after the other,
+        // so that chunk c's threshold overlaps the latency-bound border following / decoding of chunk c-1. Helps with 4
+        // streams on some boxes and hurts on others, hence off by default.
+        static const bool chain = getenv("ARUCOHIP_CHAIN") && atoi(getenv("ARUCOHIP_CHAIN")) != 0;
         w->wait_thr = (chain && c > 0) ? (c == 1 ? h : h->kids[c - 2])->ev_thr : nullptr;
         rc = chunk_enqueue(w, frames + (size_t)off * frame_stride, cnt, W, H, row_stride, frame_stride, frames_on_device, dp, cam,
                            out ? out + (size_t)off * cap : nullptr, cap, n_out + off, out_on_device);
@@ -772,18 +774,23 @@ static int fetch_contours(arucohip_handle* h0, int frame, std::vector<ContourDes
     if (owner) *owner = h;
     if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    uint32_t cnt[CNT_FIXED];
-    HIPCHK(h, hipMemcpyAsync(cnt, h->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    uint32_t n = std::min(cnt[CNT_CDESC], h->buf.cap_cdesc);
-    std::vector<ContourDesc> all(n);
-    if (n) {
-        HIPCHK(h, hipMemcpyAsync(all.data(), h->buf.cdesc, n * sizeof(ContourDesc), hipMemcpyDeviceToHost, h->stream));
+    // the frame's planes are consecutive; every plane owns cap_cdesc descriptor slots
+    std::vector<ContourDesc> all;
+    for (int t = 0; t < h->last_nthr; t++) {
+        const int plane = frame * h->last_nthr + t;
+        uint32_t n = 0;
+        HIPCHK(h, hipMemcpyAsync(&n, h->buf.trig_cnt + (size_t)plane * TRIG_CNT_STRIDE + TC_CDESC, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n = std::min(n, h->buf.cap_cdesc);
+        if (!n) continue;
+        const size_t at = all.size();
+        all.resize(at + n);
+        HIPCHK(h, hipMemcpyAsync(all.data() + at, h->buf.cdesc + (size_t)plane * h->buf.cap_cdesc, n * sizeof(ContourDesc), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     out->clear();
     for (auto& c : all)
-        if (c.plane / h->last_nthr == frame && c.n > 0) out->push_back(c);
+        if (c.n > 0) out->push_back(c);
     std::sort(out->begin(), out->end(), [](const ContourDesc& a, const ContourDesc& b) {
         if (a.plane != b.plane) return a.plane < b.plane;
         return a.key > b.key;
@@ -836,6 +843,7 @@ int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
         for (int i = 0; i < CNT_FIXED; i++) acc[i] = (i == CNT_STATUS) ? (acc[i] | cnt[i]) : acc[i] + cnt[i];
         for (int p = 0; p < planes; p++) {
             ntrig += tc[(size_t)p * TRIG_CNT_STRIDE] + tc[(size_t)p * TRIG_CNT_STRIDE + 1];
+            acc[1] += tc[(size_t)p * TRIG_CNT_STRIDE + TC_CDESC], acc[2] += tc[(size_t)p * TRIG_CNT_STRIDE + TC_POOL];
             nraw += rc_[(size_t)p * TRIG_CNT_STRIDE];
         }
     }

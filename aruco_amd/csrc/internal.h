@@ -5,8 +5,8 @@
 //   tiles [P][H/8+1][W/8+1] u64 binary image cv::findContours works on, 8x8-pixel tiles (1-px frame cleared, zero pad row/col)
 //   raw   [P][capR] u32x2 segment mode only: waypoint cracks {start candidate, pos << 2 | code}
 //   trig  [P][capT] u32x2 candidates that pass the run rule
-//   cdesc list           borders that passed the size filter {plane, start, hole, n, key, pool offset}
-//   pool  short2 list    contour points
+//   cdesc [P][capC]      borders that passed the size filter {plane, start, hole, n, key, pool offset}
+//   pool  [P][capPts] short2 contour points (checkpoints in front of each border's points)
 //   quads [F][capQ]      4-vertex convex polygons
 //   cands [F][capC]      ordered candidates with decode result and refined corners
 //   markers [F][capM]    arucohip_marker_t
@@ -19,14 +19,16 @@
 namespace ah {
 
 constexpr int WAVE = 64;
-constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters
+constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters (one 128-byte line per plane)
+constexpr int TC_CDESC = 2;           // words of a plane's trig_cnt line: 0 / 1 = outer / hole start candidates,
+constexpr int TC_POOL = 3;            // 2 = contour descriptors, 3 = contour points allocated (per plane: no global hot counter)
 constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
 
 enum Counter {
     CNT_UNUSED0 = 0,
-    CNT_CDESC = 1,     // number of contour descriptors
-    CNT_POOL = 2,      // contour points allocated
+    CNT_UNUSED1 = 1,
+    CNT_UNUSED2 = 2,
     CNT_STATUS = 3,    // overflow bit flags
     CNT_NCAND = 5,     // entries of the flat candidate list (all frames)
     CNT_FIXED = 8      // per-frame counters follow: [CNT_FIXED + f] = quads of frame f
@@ -124,7 +126,7 @@ struct Buffers {
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;   // per plane
     int seg_mode, grid_mask;      // contour pipeline: 0 = walkers, 1 = waypoint segments (grid spacing = grid_mask + 1)
-    uint32_t cap_cdesc, cap_pool;
+    uint32_t cap_cdesc, cap_pool;   // per plane: cdesc [P][cap_cdesc], pool [P][cap_pool]
     int cap_quads, cap_cands, cap_markers;   // per frame
 };
 

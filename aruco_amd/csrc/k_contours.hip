@@ -261,7 +261,7 @@ struct WalkArgs {
     const uint64_t* tiles;
     int tnx, tny, nplanes;
     const uint2* trig;
-    const uint32_t* trig_cnt;
+    uint32_t* trig_cnt;    // per plane line: start candidates (outer, hole), descriptors, points
     ContourDesc* cdesc;
     uint32_t* counters;
     uint32_t cap_trig, cap_cdesc, cap_pool;
@@ -348,8 +348,9 @@ __device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chun
         }
         if (!ok || (int)n <= a.min_contour) continue;
         const uint32_t ncp = (n + CK - 1) / CK;
-        uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
-        uint32_t off = atomicAdd(&a.counters[CNT_POOL], n + ncp);
+        // descriptor slot and point range from the plane's own counters (a global counter would serialise every kept border)
+        uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
+        uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], n + ncp);
         if (slot >= a.cap_cdesc) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
             continue;
@@ -358,15 +359,15 @@ __device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chun
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
             n = 0;  // keeps list consistent; a zero-length contour is ignored downstream
         } else {
-            uint32_t* dst = (uint32_t*)(a.pool + off);
+            uint32_t* dst = (uint32_t*)(a.pool + (size_t)plane * a.cap_pool + off);
             for (uint32_t q = 0; q < ncp; q++) dst[q] = ck[q];
             off += ncp;   // points follow the checkpoints
         }
         ContourDesc cd;
         cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = HOLE ? 1 : 0, cd.n = (int)n;
         cd.key = (tkey >> 16) * (uint32_t)a.width + (tkey & 0xFFFFu);
-        cd.pool_off = off;
-        a.cdesc[slot] = cd;
+        cd.pool_off = (uint32_t)plane * a.cap_pool + off;
+        a.cdesc[(size_t)plane * a.cap_cdesc + slot] = cd;
     }
 }
 
@@ -417,6 +418,7 @@ struct QuadArgs {
     short2* pool;
     Quad* quads;
     uint32_t* counters;
+    const uint32_t* trig_cnt;
     uint32_t cap_cdesc;
     int cap_quads, nthr;
     int width, height;
@@ -428,9 +430,11 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     __shared__ short2 s_out[12];
     __shared__ int s_outn;
     const int lane = threadIdx.x;
-    const uint32_t ncd = min(a.counters[CNT_CDESC], a.cap_cdesc);
+    const int plane = blockIdx.y;
+    const uint32_t ncd = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
     const int W = a.width;
-    for (uint32_t ci = blockIdx.x; ci < ncd; ci += gridDim.x) {
+    for (uint32_t cslot = blockIdx.x; cslot < ncd; cslot += gridDim.x) {
+        const uint32_t ci = (uint32_t)plane * a.cap_cdesc + cslot;
         const ContourDesc cd = a.cdesc[ci];
         const int count = cd.n;
         __syncthreads();
@@ -623,8 +627,9 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     QuadArgs a;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
+    a.trig_cnt = b.trig_cnt;
     size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(256 * 8), dim3(64), sh, s, a);
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(8, nframes * p.nthr), dim3(64), sh, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -53,7 +53,8 @@ struct SegArgs {
     ContourDesc* cdesc;
     short2* pool;
     uint32_t* counters;
-    uint32_t cap_cdesc, cap_pool;
+    uint32_t cap_cdesc, cap_pool;   // per plane
+    uint32_t* trig_cnt;             // per-plane counter lines (TC_CDESC, TC_POOL)
     int min_contour, max_contour;
 };
 
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
             if (j == i) break;
         }
         if (!ok || (int)total <= a.min_contour) continue;
-        const uint32_t slot = atomicAdd(&a.counters[CNT_CDESC], 1u);
-        const uint32_t off = atomicAdd(&a.counters[CNT_POOL], total);
+        const uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
+        const uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], total);
         if (slot >= a.cap_cdesc) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
             continue;
@@ -255,15 +256,16 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         ContourDesc cd;
         cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = hole, cd.n = (int)total;
         cd.key = (k0 >> 16) * (uint32_t)a.width + (k0 & 0xFFFFu);
-        cd.pool_off = off;
+        cd.pool_off = (uint32_t)plane * a.cap_pool + off;
+        const uint32_t gslot = (uint32_t)plane * a.cap_cdesc + slot;
         if (off + total > a.cap_pool) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
             cd.n = 0;
-            a.cdesc[slot] = cd;
+            a.cdesc[gslot] = cd;
             continue;
         }
-        a.cdesc[slot] = cd;
-        a.node[nb + i].w = slot;   // emit_kernel finds the descriptor through the start node
+        a.cdesc[gslot] = cd;
+        a.node[nb + i].w = gslot;   // emit_kernel finds the descriptor through the start node
     }
 }
 
@@ -324,7 +326,7 @@ static void fill_seg_args(SegArgs& a, const FrameGeom& g, int nplanes, const Det
     a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.cap_raw = b.cap_raw;
     a.node = b.node, a.stamp = b.stamp;
     a.hash = b.hash, a.hash_mask = b.hash_mask;
-    a.cdesc = b.cdesc, a.pool = b.pool, a.counters = b.counters, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
+    a.cdesc = b.cdesc, a.pool = b.pool, a.counters = b.counters, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool, a.trig_cnt = b.trig_cnt;
     a.min_contour = p.min_contour, a.max_contour = p.max_contour;
 }
 
