@@ -464,9 +464,9 @@ static int ensure_patches(arucohip_handle* h, const DetectParams& dp) {
     return ARUCOHIP_OK;
 }
 
-// the walkers keep one checkpoint ring per lane in HBM; (re)size it for this batch
+// the long walks keep their checkpoint rings in HBM; (re)size the space for this batch
 static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
-    size_t need = (size_t)((nplanes + 7) / 8) * 8 * WALK_BLOCKS * 64 * ((dp.max_contour + 15) / 16);
+    size_t need = walk_scratch_words(nplanes, dp);
     if (need <= h->scratch_words) return ARUCOHIP_OK;
     if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
     h->buf.walk_scratch = nullptr, h->scratch_words = 0;

@@ -51,6 +51,8 @@ struct ContourDesc {
     int32_t n;         // number of points
     uint32_t key;      // raster index of the scan transition (y*W + x_trigger)
     uint32_t pool_off; // first point in pool
+    uint32_t ck_off;   // checkpoints of the border: word offset into walk_scratch, or 0xFFFFFFFF = in front of the points
+    uint32_t pad_;
 };
 
 struct Quad {
@@ -103,11 +105,11 @@ struct Buffers {
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
-    uint2* trig2;          // [P][cap_trig] candidates whose walk outlasted the first pass
+    uint2* trig2;          // [P][cap_trig] as uint4 [P][2][cap_trig/4]: state of the walks that outlasted the first pass
     uint32_t* trig2_cnt;   // [P * TRIG_CNT_STRIDE]
     ContourDesc* cdesc;
     short2* pool;
-    uint32_t* walk_scratch; // checkpoint rings of the walker lanes
+    uint32_t* walk_scratch; // checkpoint rings of the long walks [P][2][LONG_CAP][max_contour/16]
     uint4* node;            // [P][cap_raw] waypoint records of the segment pipeline
     unsigned long long* stamp; // [P][cap_raw] (start key, start node, offset) of the start that owns the node
     uint32_t* hash;         // [P][hash_mask+1] node index by waypoint key
@@ -135,6 +137,7 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
+size_t walk_scratch_words(int nplanes, const DetectParams& p);   // capacity launch_walkers needs in Buffers::walk_scratch
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

@@ -252,10 +252,12 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
     hipLaunchKernelGGL(candidates_kernel, dim3(chunks, nplanes), dim3(CAND_THREADS), 0, s, a);
 }
 
-constexpr int CK = 16;   // border steps between two checkpoints
-
-// A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
-__device__ __forceinline__ uint32_t pack_ck(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)s << 28); }
+constexpr int CK = 16;        // border steps between two checkpoints
+constexpr int LEASH = 96;     // steps every candidate gets in the first pass (a multiple of CK)
+constexpr int PROBE = 10;     // steps of the reverse probe: stays inside the 32x32 block loaded around the start
+constexpr int LW_THREADS = 256;   // second pass: one workgroup per plane and border kind
+constexpr int LW_ROUND = 64;      // steps between two compactions of the live walks of a workgroup
+constexpr uint32_t LONG_CAP = 1024;   // long walks per plane and kind (their checkpoint rings live in HBM)
 
 struct WalkArgs {
     const uint64_t* tiles;
@@ -267,107 +269,173 @@ struct WalkArgs {
     uint32_t cap_trig, cap_cdesc, cap_pool;
     int width, height;
     int min_contour, max_contour;
-    int phase;             // 0: every candidate, at most soft_max steps, longer walks are queued; 1: the queued long walks
-    uint32_t soft_max;
-    uint2* trig2;          // [P][cap_trig] candidates of long walks (same two halves)
-    uint32_t* trig2_cnt;
-    uint32_t* scratch;     // [lanes in the grid][maxck] private checkpoint ring of every walker lane
-    short2* pool;          // checkpoints of a kept border are copied in front of its point range
+    uint4* longs;          // [P][2][long_cap] walks that outlast the first pass: {tkey, pos, pos1, n | s << 16}
+    uint32_t long_cap;
+    uint32_t* trig2_cnt;   // per plane line: long walks (outer, hole)
+    uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
+    short2* pool;          // points of the kept borders; a short border keeps its checkpoints in front of its points
     int maxck;
 };
 
-// Kernel 2: one lane per start candidate. Workgroups are dealt round-robin over the 8 XCDs, so the linear block id is
-// unpacked such that all workgroups of one plane share an XCD and its L2 keeps that plane's 1-bit image (W*H/8 bytes).
-// The first half of a plane's workgroups follows outer candidates, the second half hole candidates.
+enum WalkResult { WR_BAD = 0, WR_CLOSED = 1, WR_LIMIT = 2 };
+
+// A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
+__device__ __forceinline__ uint32_t pack_ck(uint32_t pos, int s) { return (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28); }
+
+// One step of OpenCV's border follower at pixel `pos`, previous pixel in direction s, neighbourhood m (bit d = neighbour in
+// direction d set). Returns the direction of the next border pixel; *bad = the walk has proven that `tkey` is not the
+// scan's start: outer border - the pixel precedes the start in raster order; hole border - a background 4-neighbour
+// examined from this pixel precedes the trigger pixel. MIRROR: m, s and the result are directions of the x-mirrored image
+// (the reverse probe follows the same border the other way round); pos and tkey are always real coordinates.
+template <bool HOLE, bool MIRROR>
+__device__ __forceinline__ int walk_step(uint32_t m, int s, uint32_t pos, uint32_t tkey, uint32_t pos0, bool* bad) {
+    const uint32_t sh = (uint32_t)(s + 1) & 7u;
+    const uint32_t rot = ((m | (m << 8)) >> sh);
+    const int k = __builtin_ctz(rot | 0x100u);
+    if (HOLE) {
+        // examined 4-neighbours z = pos + off precede tkey iff delta = pos - tkey < -off; N < W < E < S in raster order
+        const int delta = (int)(pos - tkey);
+        bool b = false;
+        if (delta < 65536) {                       // only near or above the trigger row: rare
+            uint32_t ex = ((1u << k) - 1u) << sh;
+            ex |= ex >> 8;
+            const uint32_t bitW = MIRROR ? 1u : 16u, bitE = MIRROR ? 16u : 1u;
+            const uint32_t cm = 4u | (delta < 1 ? bitW : 0u) | (delta < -1 ? bitE : 0u) | (delta < -65536 ? 64u : 0u);
+            b = (ex & cm) != 0;
+        }
+        *bad = b;
+    } else {
+        *bad = pos < pos0;
+    }
+    return (int)((sh + (uint32_t)k) & 7u);
+}
+
+__device__ __forceinline__ uint32_t tb_assemble_mirror(uint32_t up, uint32_t mid, uint32_t dn) {
+    // directions of the x-mirrored image: E' = W, NE' = NW, N' = N, NW' = NE, W' = E, SW' = SE, S' = S, SE' = SW
+    return (mid & 1u) | ((up & 1u) << 1) | ((up & 2u) << 1) | ((up >> 2) << 3) | ((mid >> 2) << 4) | ((dn >> 2) << 5) | ((dn & 2u) << 5) | ((dn & 1u) << 7);
+}
+template <int LANES>
+__device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lane, const TileBlock& b, uint32_t pos) {
+    const int lx = (int)(pos & 0xFFFFu) - b.bx, ly = (int)(pos >> 16) - b.by;
+    const uint32_t* r = rows + (ly - 1) * LANES + lane;
+    const int sh = lx - 1;
+    return tb_assemble_mirror((r[0] >> sh) & 7u, (r[LANES] >> sh) & 7u, (r[2 * LANES] >> sh) & 7u);
+}
+
+// A closed border that passes the size filter: descriptor slot and point range from the plane's own counters (a global
+// counter would serialise every kept border). Returns the descriptor's pool offset for the checkpoints / points.
+__device__ __forceinline__ bool keep_border(const WalkArgs& a, int plane, bool hole, uint32_t tkey, uint32_t pos0, uint32_t n, uint32_t nck_in_pool,
+                                            uint32_t ck_off, uint32_t* pool_at) {
+    const uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
+    uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], n + nck_in_pool);
+    if (slot >= a.cap_cdesc) {
+        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+        return false;
+    }
+    bool ok = true;
+    if (off + n + nck_in_pool > a.cap_pool) {
+        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
+        n = 0, ok = false;  // keeps the list consistent; a zero-length contour is ignored downstream
+    }
+    *pool_at = (uint32_t)plane * a.cap_pool + off;
+    ContourDesc cd;
+    cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = hole ? 1 : 0, cd.n = (int)n;
+    cd.key = (tkey >> 16) * (uint32_t)a.width + (tkey & 0xFFFFu);
+    cd.pool_off = *pool_at + nck_in_pool;   // points follow the checkpoints
+    cd.ck_off = ck_off;                     // 0xFFFFFFFF: checkpoints sit in front of the points in the pool
+    a.cdesc[(size_t)plane * a.cap_cdesc + slot] = cd;
+    return ok;
+}
+
+// Kernel 2a: one lane per start candidate, at most LEASH steps. Workgroups are dealt round-robin over the 8 XCDs, so the
+// linear block id is unpacked such that all workgroups of one plane share an XCD and its L2 keeps that plane's tiles.
+// The first half of a plane's workgroups follows outer candidates, the second half hole candidates. Before the walk a
+// short probe follows the border the other way round: many false starts whose forward walk would take hundreds of steps
+// to meet an earlier pixel are exposed within a few steps backwards. Walks that outlast the leash are queued with their
+// state for kernel 2b; most walks (small borders, false starts) end here.
 template <bool HOLE>
-__device__ __forceinline__ void walk_list(const WalkArgs& a, int plane, int chunk, int nchunks, uint32_t* rows) {
+__device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chunk, int nchunks, uint32_t* rows, uint32_t* ck0) {
     const uint32_t half = a.cap_trig / 2;
-    const uint32_t* cnt = a.phase ? a.trig2_cnt : a.trig_cnt;
-    const uint32_t ntrig = min(cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
+    const uint32_t ntrig = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], half);
     const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
-    const uint2* list = (a.phase ? a.trig2 : a.trig) + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
-    // Phase 0 gives every candidate a short leash: most walks (small borders, false starts) end within it and the few long
-    // ones are queued for phase 1, whose waves then hold long walks only instead of one long walk and 63 idle lanes.
-    const uint32_t leash = a.phase ? 0xFFFFFFFFu : a.soft_max;
+    const uint2* list = a.trig + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
     const int lane = threadIdx.x;
-    uint32_t* ck = a.scratch + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * a.maxck;
     const uint32_t nmax = (uint32_t)a.max_contour;
+    const uint32_t lim = min((uint32_t)LEASH, nmax);
     for (uint32_t i0 = chunk * blockDim.x; i0 < ntrig; i0 += nchunks * blockDim.x) {
         const uint32_t i = i0 + lane;
         bool live = i < ntrig;
-        const uint32_t tkey = live ? list[i].y : 0x00010001u;   // y << 16 | x of the scan transition
+        const uint32_t tkey = live ? list[i].y : 0x00200020u;   // y << 16 | x of the scan transition
         const uint32_t pos0 = tkey - (HOLE ? 1u : 0u);
         TileBlock blk;
         tb_load<64>(tiles, a.tnx, a.tny, pos0, rows, lane, blk);
         uint32_t m = live ? tb_mask<64>(rows, lane, blk, pos0) : 0u;
         int s = live ? first_dir(m, HOLE ? 0 : 4) : -1;
         if (s < 0) live = false;  // isolated pixel: 1 point, never passes the size filter
-        const uint32_t pos1 = pos0 + tb_dpos(s & 7);
-        uint32_t pos = pos0, n = 0;
-        bool ok = false;
-        // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
-        while (__any(live)) {
-            if (live) {
-                if ((n & (CK - 1)) == 0) ck[n / CK] = (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28);
-                // first set neighbour counter-clockwise after the direction of the previous pixel
-                const uint32_t sh = (uint32_t)(s + 1) & 7u;
-                const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
-                const int k = __builtin_ctz(rot | 0x100u);
-                const int d = (int)((sh + (uint32_t)k) & 7u);
-                bool bad;
-                if (HOLE) {
-                    // smallest background 4-neighbour examined from this pixel (N < W < E < S in raster order)
-                    uint32_t ex = ((1u << k) - 1u) << sh;
-                    ex |= ex >> 8;
-                    const uint32_t small = (ex & 4u) ? pos - 65536u : (ex & 16u) ? pos - 1u : (ex & 1u) ? pos + 1u : (ex & 64u) ? pos + 65536u : 0xFFFFFFFFu;
-                    bad = small < tkey;
-                } else {
-                    bad = pos < pos0;
-                }
-                ++n;
-                const uint32_t npos = pos + tb_dpos(d);
-                if (bad | (n >= nmax)) {
-                    live = false;
-                } else if (n >= leash) {
-                    live = false;
-                    const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
-                    if (slot < half)
-                        a.trig2[(size_t)plane * a.cap_trig + (HOLE ? half : 0) + slot] = make_uint2(HOLE ? 1u : 0u, tkey);
-                    else
-                        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
-                } else if (npos == pos0 && pos == pos1) {
-                    live = false, ok = true;
-                } else {
-                    pos = npos;
-                    s = (d + 4) & 7;
+        // ---- reverse probe (directions of the mirrored image; the block is not re-centred: PROBE steps stay inside it)
+        {
+            uint32_t rm = live ? tb_mask_mirror<64>(rows, lane, blk, pos0) : 0u;
+            int rs = live ? first_dir(rm, HOLE ? 4 : 0) : -1;
+            bool rlive = live && rs >= 0;
+            uint32_t rpos = pos0;
+            for (int it = 0; it < PROBE && __any(rlive); it++) {
+                if (rlive) {
+                    bool bad;
+                    const int d = walk_step<HOLE, true>(rm, rs, rpos, tkey, pos0, &bad);
+                    if (bad) {
+                        live = false, rlive = false;
+                    } else {
+                        rpos += tb_dpos((4 - d) & 7);
+                        rs = (d + 4) & 7;
+                        rm = tb_mask_mirror<64>(rows, lane, blk, rpos);
+                    }
                 }
             }
-            // re-centre every lane's block as soon as one live lane reaches its block's edge (wave-uniform branch)
-            if (__any(live && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
-            if (live) m = tb_mask<64>(rows, lane, blk, pos);
         }
-        if (!ok || (int)n <= a.min_contour) continue;
-        const uint32_t ncp = (n + CK - 1) / CK;
-        // descriptor slot and point range from the plane's own counters (a global counter would serialise every kept border)
-        uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
-        uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], n + ncp);
-        if (slot >= a.cap_cdesc) {
-            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+        const uint32_t pos1 = pos0 + tb_dpos(s & 7);
+        uint32_t pos = pos0, n = 0;
+        int res = WR_BAD;
+        bool walking = live;
+        // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
+        while (__any(walking)) {
+            if (walking) {
+                if ((n & (CK - 1)) == 0) ck0[(n / CK) * 64 + lane] = pack_ck(pos, s);
+                bool bad;
+                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
+                ++n;
+                const uint32_t npos = pos + tb_dpos(d);
+                const bool closed = npos == pos0 && pos == pos1;
+                if (bad | closed | (n >= lim)) {
+                    walking = false;
+                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
+                }
+                if (!bad && !closed) pos = npos, s = (d + 4) & 7;
+            }
+            // re-centre every lane's block as soon as one live lane reaches its block's edge (wave-uniform branch)
+            if (__any(walking && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            if (walking) m = tb_mask<64>(rows, lane, blk, pos);
+        }
+        if (!live || res == WR_BAD || n >= nmax) continue;
+        if (res == WR_LIMIT) {
+            // queue the walk with its state; its checkpoints move to the ring of its queue slot
+            const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
+            if (slot < a.long_cap) {
+                const size_t q = ((size_t)plane * 2 + (HOLE ? 1 : 0)) * a.long_cap + slot;
+                a.longs[q] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
+                uint32_t* ck = a.scratch + q * a.maxck;
+                for (uint32_t c = 0; c < n / CK; c++) ck[c] = ck0[c * 64 + lane];
+            } else {
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+            }
             continue;
         }
-        if (off + n + ncp > a.cap_pool) {
-            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
-            n = 0;  // keeps list consistent; a zero-length contour is ignored downstream
-        } else {
-            uint32_t* dst = (uint32_t*)(a.pool + (size_t)plane * a.cap_pool + off);
-            for (uint32_t q = 0; q < ncp; q++) dst[q] = ck[q];
-            off += ncp;   // points follow the checkpoints
+        if ((int)n <= a.min_contour) continue;
+        const uint32_t ncp = (n + CK - 1) / CK;
+        uint32_t at;
+        if (keep_border(a, plane, HOLE, tkey, pos0, n, ncp, 0xFFFFFFFFu, &at)) {
+            uint32_t* dst = (uint32_t*)(a.pool + at);
+            for (uint32_t c = 0; c < ncp; c++) dst[c] = ck0[c * 64 + lane];
         }
-        ContourDesc cd;
-        cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = HOLE ? 1 : 0, cd.n = (int)n;
-        cd.key = (tkey >> 16) * (uint32_t)a.width + (tkey & 0xFFFFu);
-        cd.pool_off = (uint32_t)plane * a.cap_pool + off;
-        a.cdesc[(size_t)plane * a.cap_cdesc + slot] = cd;
     }
 }
 
@@ -376,10 +444,113 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
     const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
     if (plane >= a.nplanes) return;
     __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
+    __shared__ uint32_t ck0[(LEASH / CK + 1) * 64];
     if (chunk < WALK_BLOCKS / 2)
-        walk_list<false>(a, plane, chunk, WALK_BLOCKS / 2, rows);
+        walk_short<false>(a, plane, chunk, WALK_BLOCKS / 2, rows, ck0);
     else
-        walk_list<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2, rows);
+        walk_short<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2, rows, ck0);
+}
+
+// Kernel 2b: the long walks of one plane and kind, one workgroup. The walks differ widely in length (a few hundred to a
+// few thousand steps), so every LW_ROUND steps the live walks are packed into the lowest lanes of the workgroup (state
+// through LDS) and the freed lanes take the next queued walks: wavefronts stay dense instead of idling behind their
+// longest walk, and empty wavefronts only meet the barriers.
+template <bool HOLE>
+__device__ __forceinline__ void walk_long(const WalkArgs& a, int plane, uint32_t* rows, uint4* xs, uint32_t* xw, uint32_t* sh) {
+    const int kind = HOLE ? 1 : 0;
+    const uint32_t nlist = min(a.trig2_cnt[plane * TRIG_CNT_STRIDE + kind], a.long_cap);
+    if (nlist == 0) return;
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
+    const size_t qbase = ((size_t)plane * 2 + kind) * a.long_cap;
+    const uint4* list = a.longs + qbase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nmax = (uint32_t)a.max_contour;
+    bool live = false;
+    uint32_t tkey = 0, pos = 0x00200020u, pos1 = 0, n = 0, wid = 0;
+    int s = 0;
+    if (tid == 0) sh[4] = 0;   // next queue entry
+    for (;;) {
+        // ---- pack the live walks, refill from the queue
+        const unsigned long long bal = __ballot(live);
+        if (lane == 0) sh[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t base = 0, L = 0;
+        for (int w = 0; w < LW_THREADS / 64; w++) {
+            const uint32_t c = sh[w];
+            if (w < wave) base += c;
+            L += c;
+        }
+        const uint32_t next = sh[4];
+        if (live) {
+            const uint32_t di = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            xs[di] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
+            xw[di] = wid;
+        }
+        __syncthreads();
+        const uint32_t take = min((uint32_t)LW_THREADS - L, nlist - next);
+        if (L + take == 0) break;
+        if (tid == 0) sh[4] = next + take;
+        live = (uint32_t)tid < L + take;
+        if (live) {
+            const bool fresh = (uint32_t)tid >= L;
+            const uint4 st = fresh ? list[next + tid - L] : xs[tid];
+            wid = fresh ? next + tid - L : xw[tid];
+            tkey = st.x, pos = st.y, pos1 = st.z, n = st.w & 0xFFFFu, s = (int)(st.w >> 16);
+        }
+        const uint32_t pos0 = tkey - (HOLE ? 1u : 0u);
+        uint32_t* ck = a.scratch + (qbase + wid) * a.maxck;
+        // ---- up to LW_ROUND steps, the lanes of a wave step together
+        if (__any(live)) {
+            TileBlock blk;
+            tb_load<LW_THREADS>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
+            uint32_t m = live ? tb_mask<LW_THREADS>(rows, tid, blk, pos) : 0u;
+            const uint32_t lim = min(n + (uint32_t)LW_ROUND, nmax);
+            bool walking = live;
+            int res = WR_LIMIT;
+            while (__any(walking)) {
+                if (walking) {
+                    if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(pos, s);
+                    bool bad;
+                    const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
+                    ++n;
+                    const uint32_t npos = pos + tb_dpos(d);
+                    const bool closed = npos == pos0 && pos == pos1;
+                    if (bad | closed | (n >= lim)) {
+                        walking = false;
+                        res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
+                    }
+                    if (!bad && !closed) pos = npos, s = (d + 4) & 7;
+                }
+                if (__any(walking && !tb_inside(blk, pos))) tb_load<LW_THREADS>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
+                if (walking) m = tb_mask<LW_THREADS>(rows, tid, blk, pos);
+            }
+            if (live) {
+                if (res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
+                    uint32_t at;
+                    keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((qbase + wid) * a.maxck), &at);
+                }
+                if (res != WR_LIMIT || n >= nmax) live = false;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LW_THREADS) void walker_long_kernel(WalkArgs a) {
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int kind = rest & 1, plane = (rest >> 1) * 8 + xcd;
+    if (plane >= a.nplanes) return;
+    __shared__ uint32_t rows[TB_ROWS * LW_THREADS];   // one 32x32-pixel block per lane
+    __shared__ uint4 xs[LW_THREADS];
+    __shared__ uint32_t xw[LW_THREADS];
+    __shared__ uint32_t sh[8];
+    if (kind == 0)
+        walk_long<false>(a, plane, rows, xs, xw, sh);
+    else
+        walk_long<true>(a, plane, rows, xs, xw, sh);
+}
+
+size_t walk_scratch_words(int nplanes, const DetectParams& p) {
+    return (size_t)((nplanes + 7) / 8) * 8 * 2 * LONG_CAP * ((p.max_contour + CK - 1) / CK);
 }
 
 void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
@@ -389,13 +560,12 @@ void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const Detect
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
-    a.trig2 = b.trig2, a.trig2_cnt = b.trig2_cnt;
-    a.soft_max = 96;
+    a.longs = (uint4*)b.trig2, a.trig2_cnt = b.trig2_cnt;
+    a.long_cap = std::min<uint32_t>(LONG_CAP, b.cap_trig / 4);   // trig2 holds [P][cap_trig] uint2 = [P][2][cap_trig/4] uint4
+    const int planes8 = ((nplanes + 7) / 8) * 8;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
-    a.phase = 0;
-    hipLaunchKernelGGL(walker_kernel, dim3(((nplanes + 7) / 8) * 8 * WALK_BLOCKS), dim3(64), 0, s, a);
-    a.phase = 1;
-    hipLaunchKernelGGL(walker_kernel, dim3(((nplanes + 7) / 8) * 8 * WALK_BLOCKS), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(walker_kernel, dim3(planes8 * WALK_BLOCKS), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(walker_long_kernel, dim3(planes8 * 2), dim3(LW_THREADS), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,6 +589,7 @@ struct QuadArgs {
     Quad* quads;
     uint32_t* counters;
     const uint32_t* trig_cnt;
+    const uint32_t* walk_scratch;   // checkpoint rings of the long walks
     uint32_t cap_cdesc;
     int cap_quads, nthr;
     int width, height;
@@ -445,7 +616,7 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
         } else {
             const uint64_t* tiles = a.tiles + (size_t)cd.plane * a.tnx * a.tny;
             const int ncp = (count + CK - 1) / CK;
-            const uint32_t* ckp = (const uint32_t*)(a.pool + cd.pool_off) - ncp;
+            const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
             for (int k = lane; k < ncp; k += WAVE) {
                 const uint32_t c = ckp[k];
                 uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
@@ -627,7 +798,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     QuadArgs a;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
-    a.trig_cnt = b.trig_cnt;
+    a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
     size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
     hipLaunchKernelGGL(contour_quad_kernel, dim3(8, nframes * p.nthr), dim3(64), sh, s, a);
 }

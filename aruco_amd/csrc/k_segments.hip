@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         cd.plane = plane, cd.x0 = (int16_t)(pos0 & 0xFFFFu), cd.y0 = (int16_t)(pos0 >> 16), cd.hole = hole, cd.n = (int)total;
         cd.key = (k0 >> 16) * (uint32_t)a.width + (k0 & 0xFFFFu);
         cd.pool_off = (uint32_t)plane * a.cap_pool + off;
+        cd.ck_off = 0xFFFFFFFFu, cd.pad_ = 0;
         const uint32_t gslot = (uint32_t)plane * a.cap_cdesc + slot;
         if (off + total > a.cap_pool) {
             atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
