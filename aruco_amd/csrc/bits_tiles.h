@@ -65,10 +65,9 @@ struct TileBlock {
     int bx, by;   // pixel origin of the block (multiples of 8)
 };
 
+// load the block whose top-left tile is (tx0, ty0); the caller keeps it inside the tile array (0 <= tx0 <= tnx-4, same in y)
 template <int LANES>
-__device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, uint32_t* rows, int lane, TileBlock& b) {
-    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
-    const int tx0 = min(max((x - 12) >> 3, 0), tnx - 4), ty0 = min(max((y - 12) >> 3, 0), tny - 4);
+__device__ __forceinline__ void tb_load_at(const uint64_t* __restrict__ tiles, int tnx, int tx0, int ty0, uint32_t* rows, int lane, TileBlock& b) {
     b.bx = tx0 * 8, b.by = ty0 * 8;
     const uint64_t* p = tiles + (size_t)ty0 * tnx + tx0;
 #pragma unroll
@@ -88,6 +87,14 @@ __device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int 
             }
         }
     }
+}
+
+// block centred on pos: after the load pos is at least 11 pixels from every edge of the block (image borders aside)
+template <int LANES>
+__device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, uint32_t* rows, int lane, TileBlock& b) {
+    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+    const int tx0 = min(max((x - 12) >> 3, 0), tnx - 4), ty0 = min(max((y - 12) >> 3, 0), tny - 4);
+    tb_load_at<LANES>(tiles, tnx, tx0, ty0, rows, lane, b);
 }
 
 __device__ __forceinline__ bool tb_inside(const TileBlock& b, uint32_t pos) {

@@ -571,14 +571,45 @@ void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const Detect
 // ---------------------------------------------------------------------------------------------
 // Kernel 3: one wave per surviving border: emit points, approxPolyDP, convexity, min side -> Quad
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
+// Wave reductions on the DPP network (no LDS crossbar trips): butterfly inside each row of 16 lanes, then row
+// broadcasts; the result is read from lane 63.
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v, int ctrl, int row_mask) {
+    switch (ctrl) {   // the control word must be an immediate
+        case 0xB1: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        case 0x4E: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        case 0x141: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+        case 0x140: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+        case 0x142: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+        default: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
     }
-    return v;
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_u32(v, v, 0xB1, 0xF));
+    v = max(v, dpp_u32(v, v, 0x4E, 0xF));
+    v = max(v, dpp_u32(v, v, 0x141, 0xF));
+    v = max(v, dpp_u32(v, v, 0x140, 0xF));
+    v = max(v, dpp_u32(v, v, 0x142, 0xA));
+    v = max(v, dpp_u32(v, v, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32(v, v, 0xB1, 0xF));
+    v = min(v, dpp_u32(v, v, 0x4E, 0xF));
+    v = min(v, dpp_u32(v, v, 0x141, 0xF));
+    v = min(v, dpp_u32(v, v, 0x140, 0xF));
+    v = min(v, dpp_u32(v, v, 0x142, 0xA));
+    v = min(v, dpp_u32(v, v, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// argmax with first-maximum tie break: every lane brings its best (value, position), positions are unique;
+// a lane without an element brings position 0xFFFFFFFF (its value is ignored)
+__device__ __forceinline__ void wave_argmax_first(uint32_t val, uint32_t idx, uint32_t* max_val, uint32_t* first_idx) {
+    const uint32_t mv = wave_max_u32(idx == 0xFFFFFFFFu ? 0u : val);
+    *max_val = mv;
+    *first_idx = wave_min_u32((idx != 0xFFFFFFFFu && val == mv) ? idx : 0xFFFFFFFFu);
+}
+
+constexpr int QP_LDS = 1024;   // points of a border kept in LDS; longer borders are scanned in HBM (their pool range)
 
 struct QuadArgs {
     const uint64_t* tiles;
@@ -595,202 +626,213 @@ struct QuadArgs {
     int width, height;
 };
 
+// One border -> at most one quad. P holds the border's points: LDS (LDSP, up to QP_LDS points) or the border's own pool range.
+template <bool LDSP>
+__device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourDesc& cd, const uint32_t ci, short2* P, int (*s_stack)[2], short2* s_out,
+                                               int& s_outn) {
+    const int lane = threadIdx.x;
+    const int count = cd.n;
+    const int W = a.width;
+    // ---- points: already emitted (segment pipeline) or every lane resumes the walk at one checkpoint and records CK points
+    if (a.from_pool) {
+        if (LDSP)
+            for (int i = lane; i < count; i += WAVE) P[i] = a.pool[cd.pool_off + i];
+    } else {
+        const uint64_t* tiles = a.tiles + (size_t)cd.plane * a.tnx * a.tny;
+        const int ncp = (count + CK - 1) / CK;
+        const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
+        for (int k = lane; k < ncp; k += WAVE) {
+            const uint32_t c = ckp[k];
+            uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
+            int s = (int)(c >> 28);
+            uint32_t m = tb_mask_direct(tiles, a.tnx, pos);
+            const int n0 = k * CK, n1 = min(n0 + CK, count);
+            for (int n = n0; n < n1; n++) {
+                const uint32_t sh = (uint32_t)(s + 1) & 7u;
+                const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
+                const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
+                P[n] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
+                pos += tb_dpos(d);
+                s = (d + 4) & 7;
+                if (n + 1 < n1) m = tb_mask_direct(tiles, a.tnx, pos);
+            }
+        }
+    }
+    __syncthreads();
+    if (LDSP && !a.from_pool)
+        for (int i = lane; i < count; i += WAVE) a.pool[cd.pool_off + i] = P[i];
+
+    // ---- cv::approxPolyDP(closed), restated for a wavefront: every "farthest point" scan is a 64-lane argmax with
+    // first-maximum tie break (lowest scan position), control flow is wave-uniform.
+    double eps = (double)count * 0.05;
+    eps *= eps;
+    int pos = 0, rs_start = 0;
+    bool le_eps = false;
+    for (int it = 0; it < 3; it++) {
+        pos = (pos + rs_start) % count;
+        const short2 sp = P[pos];
+        uint32_t bd = 0, bj = 0xFFFFFFFFu;
+        for (int j = 1 + lane; j < count; j += WAVE) {
+            int q = pos + j;
+            if (q >= count) q -= count;
+            short2 pt = P[q];
+            int dx = pt.x - sp.x, dy = pt.y - sp.y;
+            const uint32_t d2 = (uint32_t)(dx * dx + dy * dy);
+            if (d2 > bd || bj == 0xFFFFFFFFu) bd = d2, bj = (uint32_t)j;
+        }
+        uint32_t maxd, jmax;
+        wave_argmax_first(bd, bj, &maxd, &jmax);
+        if (maxd > 0) rs_start = (int)jmax;
+        le_eps = (double)maxd <= eps;
+    }
+    int top = 0, outn = 0;
+    bool reject = false;
+    if (lane == 0) s_outn = 0;
+    if (!le_eps) {
+        int sl_start = pos % count;
+        int sl_end = (rs_start + sl_start) % count;
+        if (lane == 0) {
+            s_stack[0][0] = sl_end, s_stack[0][1] = sl_start;   // right_slice
+            s_stack[1][0] = sl_start, s_stack[1][1] = sl_end;   // slice
+        }
+        top = 2;
+    } else {
+        if (lane == 0) s_out[0] = P[pos];
+        outn = 1;
+    }
+    __syncthreads();
+    while (top > 0) {
+        if (outn + top > 8) {  // cannot end as 4 vertices (clean-up removes at most every other vertex)
+            reject = true;
+            break;
+        }
+        --top;
+        const int sl_start = s_stack[top][0], sl_end = s_stack[top][1];
+        __syncthreads();
+        const short2 ep = P[sl_end], sp = P[sl_start];
+        int len = sl_end - sl_start;
+        if (len <= 0) len += count;
+        bool small;
+        int split = 0;
+        if (len > 1) {
+            const int dx = ep.x - sp.x, dy = ep.y - sp.y;
+            uint32_t bd = 0, bq = 0xFFFFFFFFu;
+            for (int q = lane; q < len - 1; q += WAVE) {
+                int idx = sl_start + 1 + q;
+                if (idx >= count) idx -= count;
+                short2 pt = P[idx];
+                int cr = (pt.y - sp.y) * dx - (pt.x - sp.x) * dy;
+                uint32_t ad = (uint32_t)(cr < 0 ? -cr : cr);
+                if (ad > bd || bq == 0xFFFFFFFFu) bd = ad, bq = (uint32_t)q;
+            }
+            uint32_t maxd_u, qmax;
+            wave_argmax_first(bd, bq, &maxd_u, &qmax);
+            double maxd = (double)maxd_u;
+            int q = qmax == 0xFFFFFFFFu ? 0 : (int)qmax;
+            split = sl_start + 1 + q;
+            if (split >= count) split -= count;
+            small = maxd * maxd <= eps * ((double)dx * (double)dx + (double)dy * (double)dy);
+        } else {
+            small = true;
+        }
+        if (small) {
+            if (lane == 0) s_out[outn] = sp;
+            outn++;
+        } else {
+            if (lane == 0) {
+                s_stack[top][0] = split, s_stack[top][1] = sl_end;
+                s_stack[top + 1][0] = sl_start, s_stack[top + 1][1] = split;
+            }
+            top += 2;
+        }
+        __syncthreads();
+    }
+    if (reject || outn < 4) return;
+    // ---- clean-up pass + convexity + min side, lane 0 (<= 8 vertices)
+    if (lane == 0) {
+        int new_count = outn;
+        const int cnt = outn;
+        int p2 = cnt - 1;
+        short2 start_pt = s_out[p2];
+        if (++p2 >= cnt) p2 = 0;
+        int wpos = p2;
+        short2 pt = s_out[p2];
+        if (++p2 >= cnt) p2 = 0;
+        for (int i = 0; i < cnt && new_count > 2; i++) {
+            short2 end_pt = s_out[p2];
+            if (++p2 >= cnt) p2 = 0;
+            double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+            double dist = fabs((double)(pt.x - start_pt.x) * dy - (double)(pt.y - start_pt.y) * dx);
+            double sip = (double)(pt.x - start_pt.x) * (double)(end_pt.x - pt.x) +
+                         (double)(pt.y - start_pt.y) * (double)(end_pt.y - pt.y);
+            if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+                new_count--;
+                s_out[wpos] = start_pt = end_pt;
+                if (++wpos >= cnt) wpos = 0;
+                pt = s_out[p2];
+                if (++p2 >= cnt) p2 = 0;
+                i++;
+                continue;
+            }
+            s_out[wpos] = start_pt = pt;
+            if (++wpos >= cnt) wpos = 0;
+            pt = end_pt;
+        }
+        bool ok = new_count == 4;
+        if (ok) {  // cv::isContourConvex on 4 int points
+            short2 prev = s_out[2], cur = s_out[3];
+            int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
+            for (int i = 0; i < 4 && ok; i++) {
+                prev = cur;
+                cur = s_out[i];
+                int dx = cur.x - prev.x, dy = cur.y - prev.y;
+                int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+                orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+                if (orientation == 3) ok = false;
+                dx0 = dx, dy0 = dy;
+            }
+        }
+        if (ok) {  // minimum side > 10 px (intended form of markerdetector.cpp:542-552)
+            int mind2 = 0x7FFFFFFF;
+            for (int j = 0; j < 4; j++) {
+                int dx = s_out[j].x - s_out[(j + 1) & 3].x, dy = s_out[j].y - s_out[(j + 1) & 3].y;
+                mind2 = min(mind2, dx * dx + dy * dy);
+            }
+            ok = mind2 > 100;
+        }
+        if (ok) {
+            const int frame = cd.plane / a.nthr, t = cd.plane - frame * a.nthr;
+            uint32_t slot = atomicAdd(&a.counters[CNT_FIXED + frame], 1u);
+            if (slot < (uint32_t)a.cap_quads) {
+                Quad q;
+                for (int j = 0; j < 4; j++) q.x[j] = s_out[j].x, q.y[j] = s_out[j].y;
+                q.cdesc = (int)ci;
+                q.key = ((uint32_t)t << 26) | (0x3FFFFFFu - cd.key);
+                q.pad_ = 0;
+                a.quads[(size_t)frame * a.cap_quads + slot] = q;
+            } else {
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_QUAD_OVERFLOW);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
-    extern __shared__ __align__(16) short2 P[];   // contour points
+    __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
     __shared__ int s_outn;
-    const int lane = threadIdx.x;
     const int plane = blockIdx.y;
     const uint32_t ncd = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
-    const int W = a.width;
     for (uint32_t cslot = blockIdx.x; cslot < ncd; cslot += gridDim.x) {
         const uint32_t ci = (uint32_t)plane * a.cap_cdesc + cslot;
         const ContourDesc cd = a.cdesc[ci];
-        const int count = cd.n;
         __syncthreads();
-        if (count <= 0) continue;
-        // ---- points: already emitted (segment pipeline) or every lane resumes the walk at one checkpoint and records CK points
-        if (a.from_pool) {
-            for (int i = lane; i < count; i += WAVE) P[i] = a.pool[cd.pool_off + i];
-        } else {
-            const uint64_t* tiles = a.tiles + (size_t)cd.plane * a.tnx * a.tny;
-            const int ncp = (count + CK - 1) / CK;
-            const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
-            for (int k = lane; k < ncp; k += WAVE) {
-                const uint32_t c = ckp[k];
-                uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
-                int s = (int)(c >> 28);
-                uint32_t m = tb_mask_direct(tiles, a.tnx, pos);
-                const int n0 = k * CK, n1 = min(n0 + CK, count);
-                for (int n = n0; n < n1; n++) {
-                    const uint32_t sh = (uint32_t)(s + 1) & 7u;
-                    const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
-                    const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
-                    P[n] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
-                    pos += tb_dpos(d);
-                    s = (d + 4) & 7;
-                    if (n + 1 < n1) m = tb_mask_direct(tiles, a.tnx, pos);
-                }
-            }
-        }
-        __syncthreads();
-        if (!a.from_pool)
-            for (int i = lane; i < count; i += WAVE) a.pool[cd.pool_off + i] = P[i];
-
-        // ---- cv::approxPolyDP(closed), restated for a wavefront: every "farthest point" scan is a 64-lane argmax with
-        // first-maximum tie break (lowest scan position), control flow is wave-uniform.
-        double eps = (double)count * 0.05;
-        eps *= eps;
-        int pos = 0, rs_start = 0;
-        bool le_eps = false;
-        for (int it = 0; it < 3; it++) {
-            pos = (pos + rs_start) % count;
-            const short2 sp = P[pos];
-            unsigned long long best = 0;
-            for (int j = 1 + lane; j < count; j += WAVE) {
-                int q = pos + j;
-                if (q >= count) q -= count;
-                short2 pt = P[q];
-                int dx = pt.x - sp.x, dy = pt.y - sp.y;
-                unsigned long long key = ((unsigned long long)(uint32_t)(dx * dx + dy * dy) << 32) | (uint32_t)(0x7FFFFFFF - j);
-                best = key > best ? key : best;
-            }
-            best = wave_max_u64(best);
-            uint32_t maxd = (uint32_t)(best >> 32);
-            if (maxd > 0) rs_start = 0x7FFFFFFF - (int)(uint32_t)(best & 0xFFFFFFFFu);
-            le_eps = (double)maxd <= eps;
-        }
-        int top = 0, outn = 0;
-        bool reject = false;
-        if (lane == 0) s_outn = 0;
-        if (!le_eps) {
-            int sl_start = pos % count;
-            int sl_end = (rs_start + sl_start) % count;
-            if (lane == 0) {
-                s_stack[0][0] = sl_end, s_stack[0][1] = sl_start;   // right_slice
-                s_stack[1][0] = sl_start, s_stack[1][1] = sl_end;   // slice
-            }
-            top = 2;
-        } else {
-            if (lane == 0) s_out[0] = P[pos];
-            outn = 1;
-        }
-        __syncthreads();
-        while (top > 0) {
-            if (outn + top > 8) {  // cannot end as 4 vertices (clean-up removes at most every other vertex)
-                reject = true;
-                break;
-            }
-            --top;
-            const int sl_start = s_stack[top][0], sl_end = s_stack[top][1];
-            __syncthreads();
-            const short2 ep = P[sl_end], sp = P[sl_start];
-            int len = sl_end - sl_start;
-            if (len <= 0) len += count;
-            bool small;
-            int split = 0;
-            if (len > 1) {
-                const int dx = ep.x - sp.x, dy = ep.y - sp.y;
-                unsigned long long best = 0;
-                for (int q = lane; q < len - 1; q += WAVE) {
-                    int idx = sl_start + 1 + q;
-                    if (idx >= count) idx -= count;
-                    short2 pt = P[idx];
-                    int cr = (pt.y - sp.y) * dx - (pt.x - sp.x) * dy;
-                    uint32_t ad = (uint32_t)(cr < 0 ? -cr : cr);
-                    unsigned long long key = ((unsigned long long)ad << 32) | (uint32_t)(0x7FFFFFFF - q);
-                    best = key > best ? key : best;
-                }
-                best = wave_max_u64(best);
-                double maxd = (double)(uint32_t)(best >> 32);
-                int q = 0x7FFFFFFF - (int)(uint32_t)(best & 0xFFFFFFFFu);
-                split = sl_start + 1 + q;
-                if (split >= count) split -= count;
-                small = maxd * maxd <= eps * ((double)dx * (double)dx + (double)dy * (double)dy);
-            } else {
-                small = true;
-            }
-            if (small) {
-                if (lane == 0) s_out[outn] = sp;
-                outn++;
-            } else {
-                if (lane == 0) {
-                    s_stack[top][0] = split, s_stack[top][1] = sl_end;
-                    s_stack[top + 1][0] = sl_start, s_stack[top + 1][1] = split;
-                }
-                top += 2;
-            }
-            __syncthreads();
-        }
-        if (reject || outn < 4) continue;
-        // ---- clean-up pass + convexity + min side, lane 0 (<= 8 vertices)
-        if (lane == 0) {
-            int new_count = outn;
-            const int cnt = outn;
-            int p2 = cnt - 1;
-            short2 start_pt = s_out[p2];
-            if (++p2 >= cnt) p2 = 0;
-            int wpos = p2;
-            short2 pt = s_out[p2];
-            if (++p2 >= cnt) p2 = 0;
-            for (int i = 0; i < cnt && new_count > 2; i++) {
-                short2 end_pt = s_out[p2];
-                if (++p2 >= cnt) p2 = 0;
-                double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
-                double dist = fabs((double)(pt.x - start_pt.x) * dy - (double)(pt.y - start_pt.y) * dx);
-                double sip = (double)(pt.x - start_pt.x) * (double)(end_pt.x - pt.x) +
-                             (double)(pt.y - start_pt.y) * (double)(end_pt.y - pt.y);
-                if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
-                    new_count--;
-                    s_out[wpos] = start_pt = end_pt;
-                    if (++wpos >= cnt) wpos = 0;
-                    pt = s_out[p2];
-                    if (++p2 >= cnt) p2 = 0;
-                    i++;
-                    continue;
-                }
-                s_out[wpos] = start_pt = pt;
-                if (++wpos >= cnt) wpos = 0;
-                pt = end_pt;
-            }
-            bool ok = new_count == 4;
-            if (ok) {  // cv::isContourConvex on 4 int points
-                short2 prev = s_out[2], cur = s_out[3];
-                int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
-                for (int i = 0; i < 4 && ok; i++) {
-                    prev = cur;
-                    cur = s_out[i];
-                    int dx = cur.x - prev.x, dy = cur.y - prev.y;
-                    int dxdy0 = dx * dy0, dydx0 = dy * dx0;
-                    orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
-                    if (orientation == 3) ok = false;
-                    dx0 = dx, dy0 = dy;
-                }
-            }
-            if (ok) {  // minimum side > 10 px (intended form of markerdetector.cpp:542-552)
-                int mind2 = 0x7FFFFFFF;
-                for (int j = 0; j < 4; j++) {
-                    int dx = s_out[j].x - s_out[(j + 1) & 3].x, dy = s_out[j].y - s_out[(j + 1) & 3].y;
-                    mind2 = min(mind2, dx * dx + dy * dy);
-                }
-                ok = mind2 > 100;
-            }
-            if (ok) {
-                const int frame = cd.plane / a.nthr, t = cd.plane - frame * a.nthr;
-                uint32_t slot = atomicAdd(&a.counters[CNT_FIXED + frame], 1u);
-                if (slot < (uint32_t)a.cap_quads) {
-                    Quad q;
-                    for (int j = 0; j < 4; j++) q.x[j] = s_out[j].x, q.y[j] = s_out[j].y;
-                    q.cdesc = (int)ci;
-                    q.key = ((uint32_t)t << 26) | (0x3FFFFFFu - cd.key);
-                    q.pad_ = 0;
-                    a.quads[(size_t)frame * a.cap_quads + slot] = q;
-                } else {
-                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_QUAD_OVERFLOW);
-                }
-            }
-        }
+        if (cd.n <= 0) continue;
+        if (cd.n <= QP_LDS)
+            border_to_quad<true>(a, cd, ci, Plds, s_stack, s_out, s_outn);
+        else
+            border_to_quad<false>(a, cd, ci, a.pool + cd.pool_off, s_stack, s_out, s_outn);
     }
 }
 
@@ -799,8 +841,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    size_t sh = (size_t)max(p.max_contour, 64) * sizeof(short2);
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(8, nframes * p.nthr), dim3(64), sh, s, a);
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(8, nframes * p.nthr), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

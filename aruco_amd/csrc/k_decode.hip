@@ -225,12 +225,16 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
     iM[8] = (m[0] * m[4] - m[1] * m[3]) * det;
 }
 
-// 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram
+// 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram.
+// Lane = patch column (ws <= 64; wider patches take the columns in turns), the wave walks down the rows: the column
+// terms iM[0]*x, iM[3]*x, iM[6]*x are formed once per lane and the row terms once per row, exactly the products and sums
+// cv::warpPerspective forms; four rows are in flight so that the gathers overlap.
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     __shared__ int hist[256];
     __shared__ double siM[9];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x;
+    const int W = a.width, H = a.height;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         __syncthreads();
         const uint32_t e = a.cand_list[idx];
@@ -240,11 +244,45 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         __syncthreads();
         const int ws = a.ws, npx = ws * ws;
         uint8_t* patch = a.patches + (size_t)idx * npx;
-        for (int i = lane; i < npx; i += WAVE) {
-            int y = i / ws, x = i - y * ws;
-            const uint8_t v = warp_pixel(src, a.width, a.height, a.row_stride, siM, x, y);
-            patch[i] = v;
-            atomicAdd(&hist[v], 1);
+        const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
+        for (int x = lane; x < ws; x += WAVE) {
+            const double ax = m0 * x, bx = m3 * x, cx = m6 * x;
+            for (int y0 = 0; y0 < ws; y0 += 4) {
+                uint8_t v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int y = y0 + q;
+                    // nearest-neighbour gather (BORDER_CONSTANT 0), cvRound = round-half-even. cv::warpPerspective forms
+                    // Wd = 1/W (correctly rounded), fX = X*Wd, cvRound(fX). The full IEEE division is the most expensive
+                    // part of the pixel, so the reciprocal is first taken from v_rcp_f64 + two Newton steps (a few ulp);
+                    // the rounded integers can only differ from the reference's when fX or fY lies within ~1e-11 of a
+                    // rounding boundary, and every pixel within 1e-6 of one (or out of range) takes the exact path.
+                    const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
+                    const double Wq = W0 + cx, nx = X0 + ax, ny = Y0 + bx;
+                    double r = __builtin_amdgcn_rcp(Wq);
+                    r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+                    r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+                    double fX = nx * r, fY = ny * r;
+                    const bool sure = fabs(__builtin_amdgcn_fract(fX) - 0.5) > 1e-6 && fabs(__builtin_amdgcn_fract(fY) - 0.5) > 1e-6 &&
+                                      fabs(fX) < 1e9 && fabs(fY) < 1e9;
+                    if (!sure) {
+                        const double Wd = Wq != 0 ? 1. / Wq : 0;
+                        fX = fmax((double)INT_MIN, fmin((double)INT_MAX, nx * Wd));
+                        fY = fmax((double)INT_MIN, fmin((double)INT_MAX, ny * Wd));
+                    }
+                    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+                    v[q] = 0;
+                    if (y < ws && X >= 0 && X < W && Y >= 0 && Y < H) v[q] = src[(size_t)Y * a.row_stride + X];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int y = y0 + q;
+                    if (y < ws) {
+                        patch[y * ws + x] = v[q];
+                        atomicAdd(&hist[v[q]], 1);
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int i = lane; i < 256; i += WAVE) a.hist[(size_t)i * a.cap_flat + idx] = (uint16_t)hist[i];
