@@ -69,6 +69,8 @@ struct arucohip_handle {
     bool is_child = false;
     std::vector<arucohip_handle*> kids;
     hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+    hipStream_t side_stream = nullptr;   // late walker generations (k_contours.hip)
+    hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     hipEvent_t ev_thr = nullptr;         // this worker's threshold kernel has finished (staggers the chunks, see detect_batch)
     hipEvent_t wait_thr = nullptr;       // set by detect_batch: event the next threshold kernel waits for
     int last_chunks = 1, last_per = 0;   // chunks and frames per chunk of the last batch
@@ -153,9 +155,12 @@ static void free_all(arucohip_handle* h) {
     h->kids.clear();
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_thr) hipEventDestroy(h->ev_thr);
+    if (h->ev_wfork) hipEventDestroy(h->ev_wfork);
+    if (h->ev_wjoin) hipEventDestroy(h->ev_wjoin);
+    if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
-    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.trig2), hipFree(h->buf.trig2_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.trig2), hipFree(h->buf.trig2_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -243,6 +248,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig2, P * (size_t)b.cap_trig * sizeof(uint2));
     ALLOC(b.trig2_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
+    ALLOC(b.gen_cnt, GEN_CNT_WORDS * sizeof(uint32_t));
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
@@ -268,6 +274,9 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
         for (auto& ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
     if ((e = hipEventCreateWithFlags(&h->ev_thr, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&h->ev_wfork, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&h->ev_wjoin, hipEventDisableTiming)) != hipSuccess) return bail(e);
     if (h->nsub > 1) {
         if ((e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e);
         for (int i = 0; i < h->nsub - 1; i++) {
@@ -475,6 +484,17 @@ static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectPara
     return ARUCOHIP_OK;
 }
 
+static void run_walkers_and_quads(arucohip_handle* h, hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& dp) {
+    static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
+    WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin};
+    const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, h->buf);
+    launch_contour_quads(s, g, nframes, dp, h->buf, forked ? 1 : 0);
+    if (forked) {
+        (void)hipStreamWaitEvent(s, h->ev_wjoin, 0);
+        launch_contour_quads(s, g, nframes, dp, h->buf, 2);
+    }
+}
+
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
     if (h->buf.seg_mode) {
@@ -483,9 +503,9 @@ static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, 
         launch_segments(h->stream, g, nframes * dp.nthr, dp, h->buf);
     } else {
         launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
-        launch_walkers(h->stream, g, nframes * dp.nthr, dp, h->buf);
+        run_walkers_and_quads(h, h->stream, g, nframes, dp);
     }
-    launch_contour_quads(h->stream, g, nframes, dp, h->buf);
+    if (h->buf.seg_mode) launch_contour_quads(h->stream, g, nframes, dp, h->buf);
     launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
 }
 
@@ -502,6 +522,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.raw_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.trig2_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
+    HIPCHK(h, hipMemsetAsync(b.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), s));
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
@@ -518,10 +539,22 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     } else {
         launch_start_candidates(s, g, nframes * dp.nthr, b);
         MARK(2);
-        launch_walkers(s, g, nframes * dp.nthr, dp, b);
     }
-    MARK(3);
-    launch_contour_quads(s, g, nframes, dp, b);
+    if (b.seg_mode) {
+        MARK(3);
+        launch_contour_quads(s, g, nframes, dp, b);
+    } else {
+        // walkers; their late generations run on the side stream under the first quad pass (MARK(3) sits at the fork)
+        static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
+        WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin};
+        const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, b);
+        MARK(3);
+        launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
+        if (forked) {
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
+            launch_contour_quads(s, g, nframes, dp, b, 2);
+        }
+    }
     MARK(4);
     launch_frame_candidates(s, g, nframes, dp, b);
     MARK(5);
@@ -878,6 +911,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig2_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
     HIPCHK(h, hipGetLastError());
@@ -905,6 +939,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig2_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
     if ((rc = ensure_walk_scratch(h, 1, dp))) return rc;
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_binary_planes(h->stream, dev, g, 1, h->buf);

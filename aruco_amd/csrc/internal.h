@@ -21,7 +21,8 @@ namespace ah {
 constexpr int WAVE = 64;
 constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters (one 128-byte line per plane)
 constexpr int TC_CDESC = 2;           // words of a plane's trig_cnt line: 0 / 1 = outer / hole start candidates,
-constexpr int TC_POOL = 3;            // 2 = contour descriptors, 3 = contour points allocated (per plane: no global hot counter)
+constexpr int TC_POOL = 3;
+constexpr int TC_SNAP = 4;            // 4 = descriptors that existed when the late walker generations were forked            // 2 = contour descriptors, 3 = contour points allocated (per plane: no global hot counter)
 constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
 
@@ -105,8 +106,9 @@ struct Buffers {
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
-    uint2* trig2;          // [P][cap_trig] as uint4 [P][2][cap_trig/4]: state of the walks that outlasted the first pass
+    uint2* trig2;          // [P][cap_trig] storage of the long-walk generation lists (states + ring ids)
     uint32_t* trig2_cnt;   // [P * TRIG_CNT_STRIDE]
+    uint32_t* gen_cnt;     // counters of the long-walk generation lists (k_contours.hip), zeroed per batch
     ContourDesc* cdesc;
     short2* pool;
     uint32_t* walk_scratch; // checkpoint rings of the long walks [P][2][LONG_CAP][max_contour/16]
@@ -119,7 +121,7 @@ struct Buffers {
     int32_t* ncands;       // [F]
     uint32_t* cand_list;   // flat list over all frames: frame << 16 | index, counters[CNT_NCAND] entries
     double* iM;            // [cap_flat][9] inverse homographies
-    uint16_t* hist;        // [256][cap_flat] patch histograms
+    uint16_t* hist;        // [cap_flat][256] patch histograms
     int32_t* othr;         // [cap_flat] Otsu thresholds
     uint8_t* patches;      // [cap_flat][warp_size^2] canonical patches
     uint32_t cap_flat;
@@ -136,10 +138,15 @@ struct Buffers {
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
-void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
+struct WalkFork {
+    hipStream_t side;            // stream of the late walker generations (nullptr: everything on the main stream)
+    hipEvent_t forked, joined;
+};
+bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 size_t walk_scratch_words(int nplanes, const DetectParams& p);   // capacity launch_walkers needs in Buffers::walk_scratch
+constexpr size_t GEN_CNT_WORDS = 2 * 32 * 32;                     // words of Buffers::gen_cnt
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
-void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, int pass = 0);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);

@@ -255,9 +255,10 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
 constexpr int CK = 16;        // border steps between two checkpoints
 constexpr int LEASH = 96;     // steps every candidate gets in the first pass (a multiple of CK)
 constexpr int PROBE = 10;     // steps of the reverse probe: stays inside the 32x32 block loaded around the start
-constexpr int LW_THREADS = 256;   // second pass: one workgroup per plane and border kind
-constexpr int LW_ROUND = 64;      // steps between two compactions of the live walks of a workgroup
 constexpr uint32_t LONG_CAP = 1024;   // long walks per plane and kind (their checkpoint rings live in HBM)
+constexpr int GEN_MAX = 30;           // generations of the long walks (kernel launches after the first pass)
+constexpr int GEN_BLOCKS = 1024;      // 64-lane workgroups per kind and generation (each loops over its share of the list)
+constexpr int GEN_CNT_STRIDE = 32;    // uint32 words between two generation counters (one 128-byte line each)
 
 struct WalkArgs {
     const uint64_t* tiles;
@@ -269,9 +270,14 @@ struct WalkArgs {
     uint32_t cap_trig, cap_cdesc, cap_pool;
     int width, height;
     int min_contour, max_contour;
-    uint4* longs;          // [P][2][long_cap] walks that outlast the first pass: {tkey, pos, pos1, n | s << 16}
-    uint32_t long_cap;
-    uint32_t* trig2_cnt;   // per plane line: long walks (outer, hole)
+    // long walks: dense lists per kind and generation parity, {tkey, pos, pos1, n | s << 16} + ring id
+    uint4* gen_state;      // [2 kinds][2 parities][gen_cap]
+    uint32_t* gen_ring;    // [2 kinds][2 parities][gen_cap]
+    uint32_t* gen_cnt;     // [(kind * (GEN_MAX + 2) + generation) * GEN_CNT_STRIDE] entries of each list
+    uint32_t gen_cap;      // entries per list
+    int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
+    uint32_t long_cap;     // rings per plane and kind
+    uint32_t* trig2_cnt;   // per plane line: rings handed out (outer, hole)
     uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
     short2* pool;          // points of the kept borders; a short border keeps its checkpoints in front of its points
     int maxck;
@@ -415,20 +421,39 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
             if (__any(walking && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
             if (walking) m = tb_mask<64>(rows, lane, blk, pos);
         }
-        if (!live || res == WR_BAD || n >= nmax) continue;
-        if (res == WR_LIMIT) {
-            // queue the walk with its state; its checkpoints move to the ring of its queue slot
-            const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
-            if (slot < a.long_cap) {
-                const size_t q = ((size_t)plane * 2 + (HOLE ? 1 : 0)) * a.long_cap + slot;
-                a.longs[q] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
-                uint32_t* ck = a.scratch + q * a.maxck;
-                for (uint32_t c = 0; c < n / CK; c++) ck[c] = ck0[c * 64 + lane];
-            } else {
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+        // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
+        {
+            bool longw = live && res == WR_LIMIT && n < nmax;
+            uint32_t ring = 0;
+            if (longw) {
+                const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
+                if (slot < a.long_cap) {
+                    ring = (uint32_t)(((size_t)plane * 2 + (HOLE ? 1 : 0)) * a.long_cap + slot);
+                    uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
+                    for (uint32_t c = 0; c < n / CK; c++) ck[c] = ck0[c * 64 + lane];
+                } else {
+                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    longw = false;
+                }
             }
-            continue;
+            const unsigned long long bal = __ballot(longw);
+            if (bal) {   // one atomic per wave on the list's counter
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&a.gen_cnt[((HOLE ? 1 : 0) * (GEN_MAX + 2) + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (longw) {
+                    const uint32_t at = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (at < a.gen_cap) {
+                        const size_t li = ((size_t)(HOLE ? 1 : 0) * 2 + 1) * a.gen_cap + at;   // parity of generation 1
+                        a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
+                        a.gen_ring[li] = ring;
+                    } else {
+                        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    }
+                }
+            }
         }
+        if (!live || res != WR_CLOSED || n >= nmax) continue;
         if ((int)n <= a.min_contour) continue;
         const uint32_t ncp = (n + CK - 1) / CK;
         uint32_t at;
@@ -451,121 +476,131 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
         walk_short<true>(a, plane, chunk - WALK_BLOCKS / 2, WALK_BLOCKS / 2, rows, ck0);
 }
 
-// Kernel 2b: the long walks of one plane and kind, one workgroup. The walks differ widely in length (a few hundred to a
-// few thousand steps), so every LW_ROUND steps the live walks are packed into the lowest lanes of the workgroup (state
-// through LDS) and the freed lanes take the next queued walks: wavefronts stay dense instead of idling behind their
-// longest walk, and empty wavefronts only meet the barriers.
+// Kernel 2b, one launch per generation: the walks that are still open after the previous generation, from all planes, as
+// one dense list per kind. Every wave takes 64 of them, walks at most gen_steps steps and appends the survivors (with
+// their state) to the next generation's list, so wavefronts are full apart from the walks that end inside a generation;
+// the generations grow from 64 steps (many walks alive) to thousands (a handful of very long borders).
 template <bool HOLE>
-__device__ __forceinline__ void walk_long(const WalkArgs& a, int plane, uint32_t* rows, uint4* xs, uint32_t* xw, uint32_t* sh) {
-    const int kind = HOLE ? 1 : 0;
-    const uint32_t nlist = min(a.trig2_cnt[plane * TRIG_CNT_STRIDE + kind], a.long_cap);
-    if (nlist == 0) return;
-    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
-    const size_t qbase = ((size_t)plane * 2 + kind) * a.long_cap;
-    const uint4* list = a.longs + qbase;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, uint32_t* rows) {
+    const int kind = HOLE ? 1 : 0, lane = threadIdx.x;
+    const uint32_t count = min(a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen) * GEN_CNT_STRIDE], a.gen_cap);
+    const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap, dst = ((size_t)kind * 2 + ((a.gen + 1) & 1)) * a.gen_cap;
     const uint32_t nmax = (uint32_t)a.max_contour;
-    bool live = false;
-    uint32_t tkey = 0, pos = 0x00200020u, pos1 = 0, n = 0, wid = 0;
-    int s = 0;
-    if (tid == 0) sh[4] = 0;   // next queue entry
-    for (;;) {
-        // ---- pack the live walks, refill from the queue
-        const unsigned long long bal = __ballot(live);
-        if (lane == 0) sh[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t base = 0, L = 0;
-        for (int w = 0; w < LW_THREADS / 64; w++) {
-            const uint32_t c = sh[w];
-            if (w < wave) base += c;
-            L += c;
-        }
-        const uint32_t next = sh[4];
-        if (live) {
-            const uint32_t di = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            xs[di] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
-            xw[di] = wid;
-        }
-        __syncthreads();
-        const uint32_t take = min((uint32_t)LW_THREADS - L, nlist - next);
-        if (L + take == 0) break;
-        if (tid == 0) sh[4] = next + take;
-        live = (uint32_t)tid < L + take;
-        if (live) {
-            const bool fresh = (uint32_t)tid >= L;
-            const uint4 st = fresh ? list[next + tid - L] : xs[tid];
-            wid = fresh ? next + tid - L : xw[tid];
-            tkey = st.x, pos = st.y, pos1 = st.z, n = st.w & 0xFFFFu, s = (int)(st.w >> 16);
-        }
-        const uint32_t pos0 = tkey - (HOLE ? 1u : 0u);
-        uint32_t* ck = a.scratch + (qbase + wid) * a.maxck;
-        // ---- up to LW_ROUND steps, the lanes of a wave step together
-        if (__any(live)) {
-            TileBlock blk;
-            tb_load<LW_THREADS>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
-            uint32_t m = live ? tb_mask<LW_THREADS>(rows, tid, blk, pos) : 0u;
-            const uint32_t lim = min(n + (uint32_t)LW_ROUND, nmax);
-            bool walking = live;
-            int res = WR_LIMIT;
-            while (__any(walking)) {
-                if (walking) {
-                    if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(pos, s);
-                    bool bad;
-                    const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
-                    ++n;
-                    const uint32_t npos = pos + tb_dpos(d);
-                    const bool closed = npos == pos0 && pos == pos1;
-                    if (bad | closed | (n >= lim)) {
-                        walking = false;
-                        res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
-                    }
-                    if (!bad && !closed) pos = npos, s = (d + 4) & 7;
+    const size_t plane_tiles = (size_t)a.tnx * a.tny;
+    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += GEN_BLOCKS * 64u) {
+        const bool live = base + lane < count;
+        const uint4 st = live ? a.gen_state[src + base + lane] : make_uint4(0x00200021u, 0x00200020u, 0u, 0u);
+        const uint32_t ring = live ? a.gen_ring[src + base + lane] : 0u;
+        const uint32_t tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
+        uint32_t pos = st.y, n = st.w & 0xFFFFu;
+        int s = (int)(st.w >> 16);
+        const int plane = (int)(ring / (2u * a.long_cap));
+        const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * plane_tiles;
+        uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
+        TileBlock blk;
+        tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+        uint32_t m = live ? tb_mask<64>(rows, lane, blk, pos) : 0u;
+        const uint32_t lim = min(n + (uint32_t)a.gen_steps, nmax);
+        bool walking = live;
+        int res = WR_LIMIT;
+        while (__any(walking)) {
+            if (walking) {
+                if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(pos, s);
+                bool bad;
+                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
+                ++n;
+                const uint32_t npos = pos + tb_dpos(d);
+                const bool closed = npos == pos0 && pos == pos1;
+                if (bad | closed | (n >= lim)) {
+                    walking = false;
+                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
                 }
-                if (__any(walking && !tb_inside(blk, pos))) tb_load<LW_THREADS>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
-                if (walking) m = tb_mask<LW_THREADS>(rows, tid, blk, pos);
+                if (!bad && !closed) pos = npos, s = (d + 4) & 7;
             }
-            if (live) {
-                if (res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
-                    uint32_t at;
-                    keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((qbase + wid) * a.maxck), &at);
-                }
-                if (res != WR_LIMIT || n >= nmax) live = false;
+            if (__any(walking && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            if (walking) m = tb_mask<64>(rows, lane, blk, pos);
+        }
+        if (live && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
+            uint32_t at;
+            keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
+        }
+        const bool again = live && res == WR_LIMIT && n < nmax;
+        const unsigned long long bal = __ballot(again);
+        if (bal) {
+            uint32_t at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+            at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+            if (again) {
+                const size_t li = dst + at0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));   // at most as many entries as this list had
+                a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
+                a.gen_ring[li] = ring;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(LW_THREADS) void walker_long_kernel(WalkArgs a) {
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int kind = rest & 1, plane = (rest >> 1) * 8 + xcd;
-    if (plane >= a.nplanes) return;
-    __shared__ uint32_t rows[TB_ROWS * LW_THREADS];   // one 32x32-pixel block per lane
-    __shared__ uint4 xs[LW_THREADS];
-    __shared__ uint32_t xw[LW_THREADS];
-    __shared__ uint32_t sh[8];
-    if (kind == 0)
-        walk_long<false>(a, plane, rows, xs, xw, sh);
+__global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
+    __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
+    if (blockIdx.x < GEN_BLOCKS)
+        walk_generation<false>(a, blockIdx.x, rows);
     else
-        walk_long<true>(a, plane, rows, xs, xw, sh);
+        walk_generation<true>(a, blockIdx.x - GEN_BLOCKS, rows);
 }
 
 size_t walk_scratch_words(int nplanes, const DetectParams& p) {
     return (size_t)((nplanes + 7) / 8) * 8 * 2 * LONG_CAP * ((p.max_contour + CK - 1) / CK);
 }
 
-void launch_walkers(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
+__global__ void snapshot_kernel(uint32_t* trig_cnt, int nplanes) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nplanes) trig_cnt[p * TRIG_CNT_STRIDE + TC_SNAP] = trig_cnt[p * TRIG_CNT_STRIDE + TC_CDESC];
+}
+
+// returns true if the late generations were forked to fk.side: the caller runs launch_contour_quads pass 1, waits for
+// fk.joined on its stream and runs pass 2
+bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
     WalkArgs a;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.nplanes = nplanes;
     a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.cdesc = b.cdesc, a.counters = b.counters;
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
-    a.longs = (uint4*)b.trig2, a.trig2_cnt = b.trig2_cnt;
-    a.long_cap = std::min<uint32_t>(LONG_CAP, b.cap_trig / 4);   // trig2 holds [P][cap_trig] uint2 = [P][2][cap_trig/4] uint4
+    a.trig2_cnt = b.trig2_cnt, a.gen_cnt = b.gen_cnt;
+    // the buffer that used to hold the second pass's candidate list now holds the generation lists:
+    // [2 kinds][2 parities][gen_cap] states (16 B) followed by the ring ids (4 B)
+    const size_t bytes = (size_t)nplanes * b.cap_trig * sizeof(uint2);
+    a.long_cap = LONG_CAP;
+    a.gen_cap = (uint32_t)std::min<size_t>(bytes / (4 * 20), (size_t)nplanes * LONG_CAP);
+    a.gen_state = (uint4*)b.trig2;
+    a.gen_ring = (uint32_t*)(a.gen_state + 4 * (size_t)a.gen_cap);
+    a.gen = 0, a.gen_steps = 0;
     const int planes8 = ((nplanes + 7) / 8) * 8;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
     hipLaunchKernelGGL(walker_kernel, dim3(planes8 * WALK_BLOCKS), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(walker_long_kernel, dim3(planes8 * 2), dim3(LW_THREADS), 0, s, a);
+    // Generations: 64-step ones while many walks are alive, then doubling. The late generations hold a handful of very long
+    // walks and are pure latency (a border of n pixels is a chain of n dependent steps), so they run on the side stream
+    // while the main stream already turns the borders found so far into quads (launch_contour_quads pass 1); the per-plane
+    // descriptor counts at the fork are snapshotted for that.
+    static const int kSteps[] = {64, 64, 64, 64, 128, 128, 128, 256, 256, 512, 512};
+    constexpr int kForkAfter = 7;
+    int done = LEASH;
+    bool forked = false;
+    hipStream_t cur = s;
+    for (int g = 1; g <= GEN_MAX && done < p.max_contour; g++) {
+        if (g == kForkAfter + 1 && fk.side) {
+            hipLaunchKernelGGL(snapshot_kernel, dim3((nplanes + 255) / 256), dim3(256), 0, s, b.trig_cnt, nplanes);
+            (void)hipEventRecord(fk.forked, s);
+            (void)hipStreamWaitEvent(fk.side, fk.forked, 0);
+            cur = fk.side, forked = true;
+        }
+        a.gen = g;
+        a.gen_steps = g <= 11 ? kSteps[g - 1] : 1024;
+        if (g == GEN_MAX) a.gen_steps = p.max_contour;   // whatever is left
+        done += a.gen_steps;
+        hipLaunchKernelGGL(walker_long_kernel, dim3(2 * GEN_BLOCKS), dim3(64), 0, cur, a);
+    }
+    if (forked) (void)hipEventRecord(fk.joined, fk.side);
+    return forked;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,6 +659,7 @@ struct QuadArgs {
     uint32_t cap_cdesc;
     int cap_quads, nthr;
     int width, height;
+    int pass;
 };
 
 // One border -> at most one quad. P holds the border's points: LDS (LDSP, up to QP_LDS points) or the border's own pool range.
@@ -823,8 +859,11 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     __shared__ short2 s_out[12];
     __shared__ int s_outn;
     const int plane = blockIdx.y;
-    const uint32_t ncd = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
-    for (uint32_t cslot = blockIdx.x; cslot < ncd; cslot += gridDim.x) {
+    // pass 0: all borders; pass 1: those that existed when the late walker generations were forked; pass 2: the rest
+    const uint32_t nall = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
+    const uint32_t nsnap = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_SNAP], a.cap_cdesc);
+    const uint32_t lo = a.pass == 2 ? nsnap : 0u, ncd = a.pass == 1 ? nsnap : nall;
+    for (uint32_t cslot = lo + blockIdx.x; cslot < ncd; cslot += gridDim.x) {
         const uint32_t ci = (uint32_t)plane * a.cap_cdesc + cslot;
         const ContourDesc cd = a.cdesc[ci];
         __syncthreads();
@@ -836,12 +875,13 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     }
 }
 
-void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, int pass) {
     QuadArgs a;
+    a.pass = pass;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(8, nframes * p.nthr), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? 2 : 8, nframes * p.nthr), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -131,7 +131,7 @@ struct DecodeArgs {
     const uint32_t* counters;    // [CNT_NCAND] = entries in cand_list
     uint32_t cap_flat;
     double* iM;                  // [cap_flat][9]
-    uint16_t* hist;              // [256][cap_flat]
+    uint16_t* hist;              // [cap_flat][256]
     int32_t* othr;               // [cap_flat]
     uint8_t* patches;            // [cap_flat][ws*ws]
 };
@@ -285,23 +285,43 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
             }
         }
         __syncthreads();
-        for (int i = lane; i < 256; i += WAVE) a.hist[(size_t)i * a.cap_flat + idx] = (uint16_t)hist[i];
+        // four bins per lane: the candidate's 512-byte histogram row is written as whole cache lines
+        ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2((uint32_t)hist[4 * lane] | ((uint32_t)hist[4 * lane + 1] << 16),
+                                                                    (uint32_t)hist[4 * lane + 2] | ((uint32_t)hist[4 * lane + 3] << 16));
     }
 }
 
-// 5c: one lane per candidate — getThreshVal_Otsu_8u, strictly sequential in double like the reference
+// 5c: one lane per candidate — getThreshVal_Otsu_8u, strictly sequential in double like the reference. The 64 histograms
+// of a workgroup are first brought into LDS with coalesced reads (bin-major, so that the lanes' sweeps read neighbouring
+// halfwords); the two 256-step sweeps then never wait for HBM.
+constexpr int OTSU_PITCH = 66;   // halfwords per bin row: 64 candidates + padding against bank conflicts
 __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
+    __shared__ uint16_t sh[256 * OTSU_PITCH];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
-    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= n) return;
+    const uint32_t base = blockIdx.x * 64;
+    if (base >= n) return;
+    const int lane = threadIdx.x;
+    const int cnt = (int)min(64u, n - base);
+    for (int c = 0; c < cnt; c++) {
+        const uint32_t* row = (const uint32_t*)(a.hist + (size_t)(base + c) * 256);
+#pragma unroll
+        for (int k = lane; k < 128; k += 64) {
+            const uint32_t v = row[k];
+            sh[(2 * k) * OTSU_PITCH + c] = (uint16_t)(v & 0xFFFFu);
+            sh[(2 * k + 1) * OTSU_PITCH + c] = (uint16_t)(v >> 16);
+        }
+    }
+    __syncthreads();
+    if (lane >= cnt) return;
+    const uint32_t idx = base + lane;
     const int npx = a.ws * a.ws;
-    const uint16_t* h = a.hist + idx;
+    const uint16_t* h = sh + lane;
     double mu = 0, scale = 1. / npx;
-    for (int i = 0; i < 256; i++) mu += i * (double)h[(size_t)i * a.cap_flat];
+    for (int i = 0; i < 256; i++) mu += i * (double)h[i * OTSU_PITCH];
     mu *= scale;
     double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
     for (int i = 0; i < 256; i++) {
-        double p_i = h[(size_t)i * a.cap_flat] * scale;
+        double p_i = h[i * OTSU_PITCH] * scale;
         mu1 *= q1;
         q1 += p_i;
         double q2 = 1. - q1;
