@@ -257,7 +257,6 @@ constexpr int LEASH = 96;     // steps every candidate gets in the first pass (a
 constexpr int PROBE = 10;     // steps of the reverse probe: stays inside the 32x32 block loaded around the start
 constexpr uint32_t LONG_CAP = 1024;   // long walks per plane and kind (their checkpoint rings live in HBM)
 constexpr int GEN_MAX = 30;           // generations of the long walks (kernel launches after the first pass)
-constexpr int GEN_BLOCKS = 1024;      // 64-lane workgroups per kind and generation (each loops over its share of the list)
 constexpr int GEN_CNT_STRIDE = 32;    // uint32 words between two generation counters (one 128-byte line each)
 
 struct WalkArgs {
@@ -276,6 +275,7 @@ struct WalkArgs {
     uint32_t* gen_cnt;     // [(kind * (GEN_MAX + 2) + generation) * GEN_CNT_STRIDE] entries of each list
     uint32_t gen_cap;      // entries per list
     int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
+    int gen_blocks;        // 64-lane workgroups per kind in this launch (each loops over its share of the list)
     uint32_t long_cap;     // rings per plane and kind
     uint32_t* trig2_cnt;   // per plane line: rings handed out (outer, hole)
     uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
@@ -326,6 +326,58 @@ __device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lan
     const uint32_t* r = rows + (ly - 1) * LANES + lane;
     const int sh = lx - 1;
     return tb_assemble_mirror((r[0] >> sh) & 7u, (r[LANES] >> sh) & 7u, (r[2 * LANES] >> sh) & 7u);
+}
+
+constexpr int CHUNK = 8;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length)
+
+// Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
+// (WR_CLOSED) or n == lim (WR_LIMIT, state advanced so that the walk can be resumed). All lanes of the wave step together.
+// The per-lane 32x32 block is re-centred (by all lanes at once) when a walking lane is within CHUNK pixels of its edge,
+// then CHUNK steps run without any edge test; n is a multiple of CHUNK at every chunk start, so checkpoints (every CK
+// steps) are only stored there. ck_at(n / CK) is where this lane's checkpoint goes.
+template <bool HOLE, int LANES, typename CkAt>
+__device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t* rows, int lane, bool live, uint32_t tkey,
+                                        uint32_t pos0, uint32_t pos1, uint32_t lim, uint32_t& pos, uint32_t& n, int& s, CkAt ck_at) {
+    TileBlock blk;
+    tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+    bool walking = live;
+    int res = WR_LIMIT;
+    const int maxbx = (tnx - 4) * 8, maxby = (tny - 4) * 8;
+    while (__any(walking)) {
+        {
+            // a side that is clamped to the image needs no margin: the border cannot leave the image
+            const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+            const int lx = x - blk.bx, ly = y - blk.by;
+            const bool near = (lx < 1 + CHUNK && blk.bx > 0) || (lx > 30 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
+                              (ly > 30 - CHUNK && blk.by < maxby);
+            if (__any(walking && near)) tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+        }
+        const uint32_t* rb = rows + lane - (blk.by + 1) * LANES;   // row y of the image sits at rb[y * LANES]
+        const int xo = -blk.bx - 1;
+#pragma unroll
+        for (int j = 0; j < CHUNK; j++) {
+            if (walking) {
+                if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(pos, s);
+                const uint32_t* r = rb + (pos >> 16) * LANES;
+                const int sh = (int)(pos & 0xFFFFu) + xo;
+                const uint32_t up = (r[0] >> sh) & 7u, mid = (r[LANES] >> sh) & 7u, dn = (r[2 * LANES] >> sh) & 7u;
+                // ring E,NE,N,NW,W,SW,S,SE: the reversed `up` lands on bits 1..3
+                const uint32_t m = (__builtin_bitreverse32(up) >> 28) | (mid >> 2) | ((mid & 1u) << 4) | (dn << 5);
+                bool bad;
+                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
+                ++n;
+                const uint32_t npos = pos + tb_dpos(d);
+                const bool closed = npos == pos0 && pos == pos1;
+                const bool stay = bad | closed;
+                if (stay | (n >= lim)) {
+                    walking = false;
+                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
+                }
+                if (!stay) pos = npos, s = (d + 4) & 7;
+            }
+        }
+    }
+    return res;
 }
 
 // A closed border that passes the size filter: descriptor slot and point range from the plane's own counters (a global
@@ -400,27 +452,10 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
         }
         const uint32_t pos1 = pos0 + tb_dpos(s & 7);
         uint32_t pos = pos0, n = 0;
-        int res = WR_BAD;
-        bool walking = live;
         // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
-        while (__any(walking)) {
-            if (walking) {
-                if ((n & (CK - 1)) == 0) ck0[(n / CK) * 64 + lane] = pack_ck(pos, s);
-                bool bad;
-                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
-                ++n;
-                const uint32_t npos = pos + tb_dpos(d);
-                const bool closed = npos == pos0 && pos == pos1;
-                if (bad | closed | (n >= lim)) {
-                    walking = false;
-                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
-                }
-                if (!bad && !closed) pos = npos, s = (d + 4) & 7;
-            }
-            // re-centre every lane's block as soon as one live lane reaches its block's edge (wave-uniform branch)
-            if (__any(walking && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
-            if (walking) m = tb_mask<64>(rows, lane, blk, pos);
-        }
+        int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, pos, n, s,
+                                     [&](uint32_t q) { return ck0 + q * 64 + lane; });
+        if (!live) res = WR_BAD;
         // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
         {
             bool longw = live && res == WR_LIMIT && n < nmax;
@@ -487,7 +522,7 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
     const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap, dst = ((size_t)kind * 2 + ((a.gen + 1) & 1)) * a.gen_cap;
     const uint32_t nmax = (uint32_t)a.max_contour;
     const size_t plane_tiles = (size_t)a.tnx * a.tny;
-    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += GEN_BLOCKS * 64u) {
+    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += (uint32_t)a.gen_blocks * 64u) {
         const bool live = base + lane < count;
         const uint4 st = live ? a.gen_state[src + base + lane] : make_uint4(0x00200021u, 0x00200020u, 0u, 0u);
         const uint32_t ring = live ? a.gen_ring[src + base + lane] : 0u;
@@ -497,29 +532,8 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
         const int plane = (int)(ring / (2u * a.long_cap));
         const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * plane_tiles;
         uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
-        TileBlock blk;
-        tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
-        uint32_t m = live ? tb_mask<64>(rows, lane, blk, pos) : 0u;
         const uint32_t lim = min(n + (uint32_t)a.gen_steps, nmax);
-        bool walking = live;
-        int res = WR_LIMIT;
-        while (__any(walking)) {
-            if (walking) {
-                if ((n & (CK - 1)) == 0) ck[n / CK] = pack_ck(pos, s);
-                bool bad;
-                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
-                ++n;
-                const uint32_t npos = pos + tb_dpos(d);
-                const bool closed = npos == pos0 && pos == pos1;
-                if (bad | closed | (n >= lim)) {
-                    walking = false;
-                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
-                }
-                if (!bad && !closed) pos = npos, s = (d + 4) & 7;
-            }
-            if (__any(walking && !tb_inside(blk, pos))) tb_load<64>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
-            if (walking) m = tb_mask<64>(rows, lane, blk, pos);
-        }
+        const int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, pos, n, s, [&](uint32_t q) { return ck + q; });
         if (live && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
             uint32_t at;
             keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
@@ -541,10 +555,10 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
 
 __global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
     __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
-    if (blockIdx.x < GEN_BLOCKS)
+    if ((int)blockIdx.x < a.gen_blocks)
         walk_generation<false>(a, blockIdx.x, rows);
     else
-        walk_generation<true>(a, blockIdx.x - GEN_BLOCKS, rows);
+        walk_generation<true>(a, blockIdx.x - a.gen_blocks, rows);
 }
 
 size_t walk_scratch_words(int nplanes, const DetectParams& p) {
@@ -597,7 +611,11 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
         a.gen_steps = g <= 11 ? kSteps[g - 1] : 1024;
         if (g == GEN_MAX) a.gen_steps = p.max_contour;   // whatever is left
         done += a.gen_steps;
-        hipLaunchKernelGGL(walker_long_kernel, dim3(2 * GEN_BLOCKS), dim3(64), 0, cur, a);
+        // enough workgroups that every wave-load of walks runs at once while many walks are alive (about a fifth of a
+        // plane's ~1000 candidates reach generation 1), fewer for the thin late generations; surplus workgroups exit at once
+        const int per_plane_x16 = g <= 2 ? 64 : g <= 4 ? 40 : g <= 7 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
+        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2));
+        hipLaunchKernelGGL(walker_long_kernel, dim3(2 * a.gen_blocks), dim3(64), 0, cur, a);
     }
     if (forked) (void)hipEventRecord(fk.joined, fk.side);
     return forked;
@@ -881,7 +899,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? 2 : 8, nframes * p.nthr), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? 4 : 8, nframes * p.nthr), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -229,8 +229,15 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
 // Lane = patch column (ws <= 64; wider patches take the columns in turns), the wave walks down the rows: the column
 // terms iM[0]*x, iM[3]*x, iM[6]*x are formed once per lane and the row terms once per row, exactly the products and sums
 // cv::warpPerspective forms; four rows are in flight so that the gathers overlap.
+// Histogram of a patch: a marker patch is two-valued, so most lanes of a row hit one of two bins and LDS atomics on one
+// histogram serialise 50-fold. 32 private copies (one per lane pair) with byte counters packed four to a word cost the same
+// 8 KB as 8 word-sized copies: a copy sees at most 2 * ws <= 128 pixels when ws <= 64, so a byte never
+// overflows into its neighbour; wider patches use word counters in 8 copies.
+constexpr int HCOPIES = 32, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+3) + 1 so that copies start in different banks
+constexpr int HWCOPIES = 8, HWPITCH = 257;
+static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
-    __shared__ int hist[256];
+    __shared__ uint32_t hist[HCOPIES * HPITCH];
     __shared__ double siM[9];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x;
@@ -239,11 +246,13 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         __syncthreads();
         const uint32_t e = a.cand_list[idx];
         const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
-        for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
+        for (int i = lane; i < HCOPIES * HPITCH; i += WAVE) hist[i] = 0;
+        const bool bytes = a.ws <= 64;
         if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
         __syncthreads();
         const int ws = a.ws, npx = ws * ws;
         uint8_t* patch = a.patches + (size_t)idx * npx;
+        uint32_t* myhist = bytes ? hist + (lane >> 1) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
         const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
         for (int x = lane; x < ws; x += WAVE) {
             const double ax = m0 * x, bx = m3 * x, cx = m6 * x;
@@ -279,15 +288,32 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
                     const int y = y0 + q;
                     if (y < ws) {
                         patch[y * ws + x] = v[q];
-                        atomicAdd(&hist[v[q]], 1);
+                        if (bytes)
+                            atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
+                        else
+                            atomicAdd(&myhist[v[q]], 1u);
                     }
                 }
             }
         }
         __syncthreads();
         // four bins per lane: the candidate's 512-byte histogram row is written as whole cache lines
-        ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2((uint32_t)hist[4 * lane] | ((uint32_t)hist[4 * lane + 1] << 16),
-                                                                    (uint32_t)hist[4 * lane + 2] | ((uint32_t)hist[4 * lane + 3] << 16));
+        uint32_t hsum[4] = {0, 0, 0, 0};
+        if (bytes) {
+            uint32_t even = 0, odd = 0;   // bins 4*lane, 4*lane+2 and 4*lane+1, 4*lane+3 as halfword pairs
+#pragma unroll
+            for (int c = 0; c < HCOPIES; c++) {
+                const uint32_t w = hist[c * HPITCH + lane];
+                even += w & 0x00FF00FFu, odd += (w >> 8) & 0x00FF00FFu;
+            }
+            hsum[0] = even & 0xFFFFu, hsum[2] = even >> 16, hsum[1] = odd & 0xFFFFu, hsum[3] = odd >> 16;
+        } else {
+#pragma unroll
+            for (int c = 0; c < HWCOPIES; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) hsum[q] += hist[c * HWPITCH + 4 * lane + q];
+        }
+        ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2(hsum[0] | (hsum[1] << 16), hsum[2] | (hsum[3] << 16));
     }
 }
 
