@@ -203,10 +203,12 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
     h->stream = h->own_stream;
     {
-        // workers: at least ~128 Mpx of frames per chunk, at most 2 (ARUCOHIP_STREAMS overrides, 1 disables). Measured on
-        // three MI355X boxes at 1024 1080p frames: 1 stream 155-158 k fps, 2 streams 174-179 k, 4 streams 145 k.
+        // workers: one by default; ARUCOHIP_STREAMS = 2..8 cuts large batches into chunks on separate streams (copies of host
+        // frames then overlap the kernels). With the late walker generations on their own side stream a second chunk stream
+        // no longer gains anything for device-resident frames (1 stream 208 k fps, 2 streams 208 k at 1024 1080p frames).
         const double mpx = (double)lim->max_batch * lim->max_width * lim->max_height / (128.0 * 1024 * 1024);
-        int ns = (int)std::min(2.0, std::max(1.0, std::floor(mpx)));
+        int ns = 1;
+        (void)mpx;
         if (const char* es = getenv("ARUCOHIP_STREAMS")) ns = std::min(8, std::max(1, atoi(es)));
         if (g_creating_child) ns = 1;
         h->is_child = g_creating_child;

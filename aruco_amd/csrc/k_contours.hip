@@ -596,7 +596,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     // while the main stream already turns the borders found so far into quads (launch_contour_quads pass 1); the per-plane
     // descriptor counts at the fork are snapshotted for that.
     static const int kSteps[] = {64, 64, 64, 64, 128, 128, 128, 256, 256, 512, 512};
-    constexpr int kForkAfter = 7;
+    const int kForkAfter = getenv("ARUCOHIP_FORK_AFTER") ? atoi(getenv("ARUCOHIP_FORK_AFTER")) : 7;   // tuning knob
     int done = LEASH;
     bool forked = false;
     hipStream_t cur = s;
@@ -899,7 +899,8 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? 4 : 8, nframes * p.nthr), dim3(64), 0, s, a);
+    const int qb = getenv("ARUCOHIP_QUAD_BLOCKS") ? std::max(1, atoi(getenv("ARUCOHIP_QUAD_BLOCKS"))) : 8;   // workgroups per plane (tuning knob)
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? std::max(1, qb / 2) : qb, nframes * p.nthr), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,11 +85,15 @@ def _marker_table(marker_id, quiet, black, white):
 
 
 def _poly_mask(shape, quad, scale):
-    """Boolean occupancy of convex quad on a grid downscaled by `scale`."""
+    """Occupancy of a convex quad on a grid downscaled by `scale`: (y0, y1, x0, x1, mask of that window)."""
     h, w = shape
     q = np.asarray(quad, float) / scale
-    ys, xs = np.mgrid[0:h, 0:w]
-    m = np.ones((h, w), bool)
+    x0 = int(max(0, math.floor(q[:, 0].min()) - 1)); x1 = int(min(w, math.ceil(q[:, 0].max()) + 2))
+    y0 = int(max(0, math.floor(q[:, 1].min()) - 1)); y1 = int(min(h, math.ceil(q[:, 1].max()) + 2))
+    if x1 <= x0 or y1 <= y0:
+        return 0, 0, 0, 0, np.zeros((0, 0), bool)
+    ys, xs = np.mgrid[y0:y1, x0:x1]
+    m = np.ones((y1 - y0, x1 - x0), bool)
     sign = 0
     for i in range(4):
         ax, ay = q[i]
@@ -99,7 +103,7 @@ def _poly_mask(shape, quad, scale):
             c = (q[:, 0].mean() - ax) * (by - ay) - (q[:, 1].mean() - ay) * (bx - ax)
             sign = -1 if c > 0 else 1
         m &= (cr * sign) >= 0
-    return m
+    return y0, y1, x0, x1, m
 
 
 def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=60, jitter=0.08, quiet=1):
@@ -143,10 +147,10 @@ def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=
             # pad the occupancy test by a few pixels so quiet zones never touch
             ctr = qq.mean(axis=0)
             grown = ctr + (qq - ctr) * (1 + 10.0 / s)
-            m = _poly_mask(occ.shape, grown, sc)
-            if (m & occ).any():
+            y0, y1, x0, x1, m = _poly_mask(occ.shape, grown, sc)
+            if (m & occ[y0:y1, x0:x1]).any():
                 continue
-            occ |= m
+            occ[y0:y1, x0:x1] |= m
             out.append({"id": int(mid), "quad": quad, "quad_q": qq})
             break
     return out

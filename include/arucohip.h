@@ -131,8 +131,8 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
                           int out_on_device);
 /* After an asynchronous batch: synchronise and report device-side overflow / capacity conditions. */
 int arucohip_batch_status(arucohip_handle* h);
-/* A large batch is processed as 2 chunks of consecutive frames on separate HIP streams (environment variable
- * ARUCOHIP_STREAMS = 1..8 overrides the count) that fork from and join the handle's stream, so the caller sees one
+/* With the environment variable ARUCOHIP_STREAMS = 2..8 a large batch is processed as that many chunks of consecutive
+ * frames on separate HIP streams (default 1) that fork from and join the handle's stream, so the caller sees one
  * stream-ordered call; host frames of chunk i+1 are copied while chunk i computes. Returns the number of chunks of the
  * last batch and, if not NULL, the frames per chunk — every kernel launch covers one chunk. No reference counterpart. */
 int arucohip_batch_chunks(arucohip_handle* h, int* frames_per_chunk);
