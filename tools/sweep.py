@@ -15,12 +15,18 @@ s = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(s)
 h.set_stream(s.cuda_stream)
 res = []
-for fork, qb in [(7, 8), (7, 16), (7, 32), (5, 16), (9, 16), (11, 16), (99, 16), (7, 8)]:
-    os.environ["ARUCOHIP_FORK_AFTER"] = str(fork)
-    os.environ["ARUCOHIP_QUAD_BLOCKS"] = str(qb)
+import ast
+SETTINGS = ast.literal_eval(os.environ.get("SWEEP", "[(7, 8), (99, 8)]"))
+for fork, qb in SETTINGS:
+    if isinstance(fork, str):
+        os.environ[fork] = str(qb)
+    else:
+        os.environ["ARUCOHIP_FORK_AFTER"] = str(fork)
+        os.environ["ARUCOHIP_QUAD_BLOCKS"] = str(qb)
     for _ in range(2):
         h.detect_batch_device(fr.data_ptr(), N, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
     h.batch_status()
+    h.enable_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(8):
@@ -28,5 +34,7 @@ for fork, qb in [(7, 8), (7, 16), (7, 32), (5, 16), (9, 16), (11, 16), (99, 16),
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 8
     h.batch_status()
-    res.append({"fork_after": fork, "quad_blocks": qb, "fps": round(N / dt, 1), "markers": round(float(cnt.float().mean()), 3)})
+    kt = {k: round(v, 3) for k, v in h.kernel_times().items() if v > 0.01}
+    h.enable_timing(False)
+    res.append({"fork_after": fork, "quad_blocks": qb, "fps": round(N / dt, 1), "markers": round(float(cnt.float().mean()), 3), "kernel_ms": kt})
     print(json.dumps(res[-1]), flush=True)
