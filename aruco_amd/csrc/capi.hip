@@ -160,7 +160,7 @@ static void free_all(arucohip_handle* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
-    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.trig2), hipFree(h->buf.trig2_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -248,8 +248,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
     ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
-    ALLOC(b.trig2, P * (size_t)b.cap_trig * sizeof(uint2));
-    ALLOC(b.trig2_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
+    ALLOC(b.gen_buf, P * (size_t)b.cap_trig * sizeof(uint2));
+    ALLOC(b.ring_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.gen_cnt, GEN_CNT_WORDS * sizeof(uint32_t));
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
@@ -523,7 +523,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.raw_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
-    HIPCHK(h, hipMemsetAsync(b.trig2_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
+    HIPCHK(h, hipMemsetAsync(b.ring_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
     HIPCHK(h, hipMemsetAsync(b.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), s));
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
@@ -912,7 +912,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.trig2_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.ring_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
@@ -940,7 +940,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.trig2_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf.ring_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
     if ((rc = ensure_walk_scratch(h, 1, dp))) return rc;
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;

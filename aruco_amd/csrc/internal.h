@@ -106,8 +106,8 @@ struct Buffers {
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
     uint32_t* trig_cnt;    // [P * TRIG_CNT_STRIDE]
-    uint2* trig2;          // [P][cap_trig] storage of the long-walk generation lists (states + ring ids)
-    uint32_t* trig2_cnt;   // [P * TRIG_CNT_STRIDE]
+    uint2* gen_buf;        // [P][cap_trig] storage of the long-walk generation lists (states + ring ids)
+    uint32_t* ring_cnt;    // [P * TRIG_CNT_STRIDE] checkpoint rings handed out per plane (outer, hole)
     uint32_t* gen_cnt;     // counters of the long-walk generation lists (k_contours.hip), zeroed per batch
     ContourDesc* cdesc;
     short2* pool;

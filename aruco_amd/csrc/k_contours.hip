@@ -253,7 +253,8 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
 }
 
 constexpr int CK = 16;        // border steps between two checkpoints
-constexpr int LEASH = 96;     // steps every candidate gets in the first pass (a multiple of CK)
+constexpr int LEASH_MAX = 96;     // most steps a candidate can get in the first pass (sizes the LDS checkpoint array)
+constexpr int LEASH_DEFAULT = 64; // a multiple of CK; ARUCOHIP_LEASH overrides for tuning
 constexpr int PROBE = 10;     // steps of the reverse probe: stays inside the 32x32 block loaded around the start
 constexpr uint32_t LONG_CAP = 1024;   // long walks per plane and kind (their checkpoint rings live in HBM)
 constexpr int GEN_MAX = 30;           // generations of the long walks (kernel launches after the first pass)
@@ -274,10 +275,11 @@ struct WalkArgs {
     uint32_t* gen_ring;    // [2 kinds][2 parities][gen_cap]
     uint32_t* gen_cnt;     // [(kind * (GEN_MAX + 2) + generation) * GEN_CNT_STRIDE] entries of each list
     uint32_t gen_cap;      // entries per list
+    int leash;             // steps every candidate gets in the first pass
     int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
     int gen_blocks;        // 64-lane workgroups per kind in this launch (each loops over its share of the list)
     uint32_t long_cap;     // rings per plane and kind
-    uint32_t* trig2_cnt;   // per plane line: rings handed out (outer, hole)
+    uint32_t* ring_cnt;   // per plane line: rings handed out (outer, hole)
     uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
     short2* pool;          // points of the kept borders; a short border keeps its checkpoints in front of its points
     int maxck;
@@ -419,7 +421,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
     const uint2* list = a.trig + (size_t)plane * a.cap_trig + (HOLE ? half : 0);
     const int lane = threadIdx.x;
     const uint32_t nmax = (uint32_t)a.max_contour;
-    const uint32_t lim = min((uint32_t)LEASH, nmax);
+    const uint32_t lim = min((uint32_t)a.leash, nmax);
     for (uint32_t i0 = chunk * blockDim.x; i0 < ntrig; i0 += nchunks * blockDim.x) {
         const uint32_t i = i0 + lane;
         bool live = i < ntrig;
@@ -461,7 +463,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
             bool longw = live && res == WR_LIMIT && n < nmax;
             uint32_t ring = 0;
             if (longw) {
-                const uint32_t slot = atomicAdd(&a.trig2_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
+                const uint32_t slot = atomicAdd(&a.ring_cnt[plane * TRIG_CNT_STRIDE + (HOLE ? 1 : 0)], 1u);
                 if (slot < a.long_cap) {
                     ring = (uint32_t)(((size_t)plane * 2 + (HOLE ? 1 : 0)) * a.long_cap + slot);
                     uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
     const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
     if (plane >= a.nplanes) return;
     __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
-    __shared__ uint32_t ck0[(LEASH / CK + 1) * 64];
+    __shared__ uint32_t ck0[(LEASH_MAX / CK + 1) * 64];
     if (chunk < WALK_BLOCKS / 2)
         walk_short<false>(a, plane, chunk, WALK_BLOCKS / 2, rows, ck0);
     else
@@ -579,15 +581,20 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     a.cap_trig = b.cap_trig, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool;
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
-    a.trig2_cnt = b.trig2_cnt, a.gen_cnt = b.gen_cnt;
+    a.ring_cnt = b.ring_cnt, a.gen_cnt = b.gen_cnt;
     // the buffer that used to hold the second pass's candidate list now holds the generation lists:
     // [2 kinds][2 parities][gen_cap] states (16 B) followed by the ring ids (4 B)
     const size_t bytes = (size_t)nplanes * b.cap_trig * sizeof(uint2);
     a.long_cap = LONG_CAP;
     a.gen_cap = (uint32_t)std::min<size_t>(bytes / (4 * 20), (size_t)nplanes * LONG_CAP);
-    a.gen_state = (uint4*)b.trig2;
+    a.gen_state = (uint4*)b.gen_buf;
     a.gen_ring = (uint32_t*)(a.gen_state + 4 * (size_t)a.gen_cap);
     a.gen = 0, a.gen_steps = 0;
+    {
+        const char* e = getenv("ARUCOHIP_LEASH");
+        const int v = e ? atoi(e) : LEASH_DEFAULT;
+        a.leash = (v >= CK && v <= LEASH_MAX && v % CK == 0) ? v : LEASH_DEFAULT;
+    }
     const int planes8 = ((nplanes + 7) / 8) * 8;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
     hipLaunchKernelGGL(walker_kernel, dim3(planes8 * WALK_BLOCKS), dim3(64), 0, s, a);
@@ -595,9 +602,24 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     // walks and are pure latency (a border of n pixels is a chain of n dependent steps), so they run on the side stream
     // while the main stream already turns the borders found so far into quads (launch_contour_quads pass 1); the per-plane
     // descriptor counts at the fork are snapshotted for that.
-    static const int kSteps[] = {64, 64, 64, 64, 128, 128, 128, 256, 256, 512, 512};
+    // schedule: ARUCOHIP_GENS="64,64,128,..." overrides for tuning; after the listed generations the length stays 1024
+    int kSteps[GEN_MAX], nsched = 0;
+    {
+        const char* e = getenv("ARUCOHIP_GENS");
+        static const int kDefault[] = {64, 64, 64, 128, 128, 256, 256, 512, 512};   // fork after 7: borders up to 1024 points are in pass 1
+        if (e && *e) {
+            for (const char* q = e; *q && nsched < GEN_MAX;) {
+                const int v = atoi(q);
+                if (v >= CHUNK && v % CHUNK == 0 && v % CK == 0) kSteps[nsched++] = v;
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
+        if (nsched == 0)
+            for (int v : kDefault) kSteps[nsched++] = v;
+    }
     const int kForkAfter = getenv("ARUCOHIP_FORK_AFTER") ? atoi(getenv("ARUCOHIP_FORK_AFTER")) : 7;   // tuning knob
-    int done = LEASH;
+    int done = a.leash;
     bool forked = false;
     hipStream_t cur = s;
     for (int g = 1; g <= GEN_MAX && done < p.max_contour; g++) {
@@ -608,7 +630,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
             cur = fk.side, forked = true;
         }
         a.gen = g;
-        a.gen_steps = g <= 11 ? kSteps[g - 1] : 1024;
+        a.gen_steps = g <= nsched ? kSteps[g - 1] : 1024;
         if (g == GEN_MAX) a.gen_steps = p.max_contour;   // whatever is left
         done += a.gen_steps;
         // enough workgroups that every wave-load of walks runs at once while many walks are alive (about a fifth of a
@@ -899,7 +921,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    const int qb = getenv("ARUCOHIP_QUAD_BLOCKS") ? std::max(1, atoi(getenv("ARUCOHIP_QUAD_BLOCKS"))) : 8;   // workgroups per plane (tuning knob)
+    const int qb = getenv("ARUCOHIP_QUAD_BLOCKS") ? std::max(1, atoi(getenv("ARUCOHIP_QUAD_BLOCKS"))) : 24;   // workgroups per plane (tuning knob; 8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? std::max(1, qb / 2) : qb, nframes * p.nthr), dim3(64), 0, s, a);
 }
 

@@ -44,6 +44,9 @@ struct LinesArgs {
     int cap_cands;
     int do_lines;
     CamModel cam;
+    const uint32_t* cand_list;   // frame << 16 | index, counters[CNT_NCAND] entries
+    const uint32_t* counters;
+    uint32_t cap_flat;
 };
 
 struct SideSums {
@@ -88,9 +91,8 @@ __device__ static void fit_line(const SideSums& s, float line[3]) {
         line[0] = -1.f, line[1] = (float)A, line[2] = (float)C;
 }
 
-__global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
-    const int frame = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= a.ncands[frame]) return;
+__device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int lane) {
+    const int frame = (int)(e >> 16), ci = (int)(e & 0xFFFFu);
     Cand* cand = a.cands + (size_t)frame * a.cap_cands + ci;
     if (cand->id < 0) return;
     float out[8];
@@ -199,12 +201,22 @@ __global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
     }
 }
 
+// one wave per decoded candidate, taken from the flat candidate list of the batch (a grid over every candidate slot of
+// every frame would be 90 % empty workgroups)
+__global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t nlist = min(a.counters[CNT_NCAND], a.cap_flat);
+    for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) refine_one(a, a.cand_list[li], lane);
+}
+
 void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
     LinesArgs a;
     a.cands = b.cands, a.ncands = b.ncands, a.cdesc = b.cdesc, a.pool = b.pool, a.cap_cands = b.cap_cands;
     a.do_lines = p.corner_method == ARUCOHIP_CORNER_LINES;
     a.cam = cam;
-    hipLaunchKernelGGL(refine_lines_kernel, dim3(b.cap_cands, nframes), dim3(64), 0, s, a);
+    a.cand_list = b.cand_list, a.counters = b.counters, a.cap_flat = b.cap_flat;
+    const int blocks = (int)std::min<uint32_t>(b.cap_flat, (uint32_t)nframes * 48u);
+    hipLaunchKernelGGL(refine_lines_kernel, dim3(blocks), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

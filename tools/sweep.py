@@ -16,13 +16,12 @@ torch.cuda.set_stream(s)
 h.set_stream(s.cuda_stream)
 res = []
 import ast
-SETTINGS = ast.literal_eval(os.environ.get("SWEEP", "[(7, 8), (99, 8)]"))
-for fork, qb in SETTINGS:
-    if isinstance(fork, str):
-        os.environ[fork] = str(qb)
-    else:
-        os.environ["ARUCOHIP_FORK_AFTER"] = str(fork)
-        os.environ["ARUCOHIP_QUAD_BLOCKS"] = str(qb)
+SETTINGS = ast.literal_eval(os.environ.get("SWEEP", "[{}]"))   # list of {ENV_NAME: value} dicts
+for setting in SETTINGS:
+    for k in [k for k in os.environ if k.startswith("ARUCOHIP_")]:
+        del os.environ[k]
+    for k, v in setting.items():
+        os.environ[k] = str(v)
     for _ in range(2):
         h.detect_batch_device(fr.data_ptr(), N, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
     h.batch_status()
@@ -36,5 +35,5 @@ for fork, qb in SETTINGS:
     h.batch_status()
     kt = {k: round(v, 3) for k, v in h.kernel_times().items() if v > 0.01}
     h.enable_timing(False)
-    res.append({"fork_after": fork, "quad_blocks": qb, "fps": round(N / dt, 1), "markers": round(float(cnt.float().mean()), 3), "kernel_ms": kt})
+    res.append({"setting": setting, "fps": round(N / dt, 1), "markers": round(float(cnt.float().mean()), 3), "kernel_ms": kt})
     print(json.dumps(res[-1]), flush=True)
