@@ -248,7 +248,8 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
     a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig;
     a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
     const int ntiles = (a.tnx - 1) * (a.tny - 1);
-    const int chunks = std::max(1, std::min(16, (ntiles + 4 * CAND_THREADS - 1) / (4 * CAND_THREADS)));
+    const int maxchunks = getenv("ARUCOHIP_CAND_CHUNKS") ? std::max(1, atoi(getenv("ARUCOHIP_CAND_CHUNKS"))) : 16;   // tuning knob
+    const int chunks = std::max(1, std::min(maxchunks, (ntiles + 4 * CAND_THREADS - 1) / (4 * CAND_THREADS)));
     hipLaunchKernelGGL(candidates_kernel, dim3(chunks, nplanes), dim3(CAND_THREADS), 0, s, a);
 }
 

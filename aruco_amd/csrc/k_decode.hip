@@ -328,13 +328,25 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     if (base >= n) return;
     const int lane = threadIdx.x;
     const int cnt = (int)min(64u, n - base);
-    for (int c = 0; c < cnt; c++) {
-        const uint32_t* row = (const uint32_t*)(a.hist + (size_t)(base + c) * 256);
+    // 8 histogram rows in flight per step (two dwords per lane and row)
+    for (int c0 = 0; c0 < cnt; c0 += 8) {
+        uint32_t v[8][2];
 #pragma unroll
-        for (int k = lane; k < 128; k += 64) {
-            const uint32_t v = row[k];
-            sh[(2 * k) * OTSU_PITCH + c] = (uint16_t)(v & 0xFFFFu);
-            sh[(2 * k + 1) * OTSU_PITCH + c] = (uint16_t)(v >> 16);
+        for (int j = 0; j < 8; j++) {
+            const uint32_t* row = (const uint32_t*)(a.hist + (size_t)(base + min(c0 + j, cnt - 1)) * 256);
+            v[j][0] = row[lane], v[j][1] = row[lane + 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = c0 + j;
+            if (c < cnt) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int k = lane + 64 * q;
+                    sh[(2 * k) * OTSU_PITCH + c] = (uint16_t)(v[j][q] & 0xFFFFu);
+                    sh[(2 * k + 1) * OTSU_PITCH + c] = (uint16_t)(v[j][q] >> 16);
+                }
+            }
         }
     }
     __syncthreads();
