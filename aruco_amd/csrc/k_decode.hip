@@ -376,60 +376,80 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
 }
 
 // 5d: one wavefront per candidate — 7x7 cell votes on the binarised patch and the 5x5 Hamming decode
+// 5x5 code as five 5-bit rows, bit x = column x (so the dictionary words of hammDistMarker are used bit-reversed)
+__device__ __forceinline__ int hamm_rows(const uint32_t v[5]) {
+    const uint32_t words[4] = {0x01, 0x1D, 0x12, 0x0E};   // 10000, 10111, 01001, 01110 reversed
+    int dist = 0;
+#pragma unroll
+    for (int y = 0; y < 5; y++) {
+        int best = 100000;
+#pragma unroll
+        for (int p = 0; p < 4; p++) best = min(best, __popc(v[y] ^ words[p]));
+        dist += best;
+    }
+    return dist;
+}
+
 __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
-    __shared__ int s_cnt[49];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
-        __syncthreads();
         const uint32_t e = a.cand_list[idx];
         Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
         const int ws = a.ws, sw = ws / 7, thr = a.othr[idx];
         const uint8_t* patch = a.patches + (size_t)idx * ws * ws;
+        const int half = (sw * sw) / 2;
+        bool white = false;
         if (lane < 49) {   // cell (cy,cx): white iff more than half of its pixels exceed the Otsu threshold
             const int cy = lane / 7, cx = lane - cy * 7;
             int cnt = 0;
-            for (int y = 0; y < sw; y++)
-                for (int x = 0; x < sw; x++) cnt += patch[(cy * sw + y) * ws + cx * sw + x] > thr;
-            s_cnt[lane] = cnt;
+            if (sw == 8 && (((size_t)patch | (size_t)ws) & 7) == 0) {   // default 56x56 patch: a cell row is one aligned 8-byte load
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const uint2 w = *(const uint2*)(patch + (cy * 8 + y) * ws + cx * 8);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) cnt += (int)((w.x >> (8 * b)) & 0xFFu) > thr, cnt += (int)((w.y >> (8 * b)) & 0xFFu) > thr;
+                }
+            } else {
+                for (int y = 0; y < sw; y++)
+                    for (int x = 0; x < sw; x++) cnt += patch[(cy * sw + y) * ws + cx * sw + x] > thr;
+            }
+            white = cnt > half;
         }
-        __syncthreads();
+        const unsigned long long m = __ballot(white);   // bit cy*7+cx
         if (lane == 0) {
             int id = -1, nrot = 0;
-            const int half = (sw * sw) / 2;
-            bool border_ok = true;
-            for (int y = 0; y < 7 && border_ok; y++) {
-                int inc = (y == 0 || y == 6) ? 1 : 6;
-                for (int x = 0; x < 7; x += inc)
-                    if (s_cnt[y * 7 + x] > half) {
-                        border_ok = false;
-                        break;
-                    }
-            }
-            if (border_ok) {
-                uint8_t rot[2][5][5];
-                for (int y = 0; y < 5; y++)
-                    for (int x = 0; x < 5; x++) rot[0][y][x] = s_cnt[(y + 1) * 7 + x + 1] > half;
-                int min_dist = hamm_dist(rot[0]);
-                uint8_t best[5][5];
-                for (int y = 0; y < 5; y++)
-                    for (int x = 0; x < 5; x++) best[y][x] = rot[0][y][x];
-                int cur = 0;
+            // checkBorders: all 24 frame cells must be black
+            unsigned long long border = 0x7Full | (0x7Full << 42);
+#pragma unroll
+            for (int y = 1; y < 6; y++) border |= (1ull << (7 * y)) | (1ull << (7 * y + 6));
+            if ((m & border) == 0) {
+                uint32_t cur[5], best[5];
+#pragma unroll
+                for (int y = 0; y < 5; y++) cur[y] = (uint32_t)(m >> (7 * (y + 1) + 1)) & 31u, best[y] = cur[y];
+                int min_dist = hamm_rows(cur);
+#pragma unroll
                 for (int r = 1; r < 4; r++) {
-                    int nxt = cur ^ 1;
-                    for (int i = 0; i < 5; i++)
-                        for (int j = 0; j < 5; j++) rot[nxt][i][j] = rot[cur][5 - j - 1][i];
-                    cur = nxt;
-                    int dd = hamm_dist(rot[cur]);
+                    uint32_t nxt[5];   // rotate: new[i][j] = old[4-j][i]
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        nxt[i] = 0;
+#pragma unroll
+                        for (int j = 0; j < 5; j++) nxt[i] |= ((cur[4 - j] >> i) & 1u) << j;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; i++) cur[i] = nxt[i];
+                    const int dd = hamm_rows(cur);
                     if (dd < min_dist) {
                         min_dist = dd, nrot = r;
-                        for (int y = 0; y < 5; y++)
-                            for (int x = 0; x < 5; x++) best[y][x] = rot[cur][y][x];
+#pragma unroll
+                        for (int i = 0; i < 5; i++) best[i] = cur[i];
                     }
                 }
                 if (min_dist == 0) {
                     id = 0;
-                    for (int y = 0; y < 5; y++) id |= (best[y][1] << 1 | best[y][3]) << 2 * (4 - y);
+#pragma unroll
+                    for (int y = 0; y < 5; y++) id |= (int)((((best[y] >> 1) & 1u) << 1) | ((best[y] >> 3) & 1u)) << (2 * (4 - y));
                 }
             }
             cand->id = id;
