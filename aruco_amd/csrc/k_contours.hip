@@ -340,9 +340,13 @@ constexpr int CHUNK = 8;   // steps taken between two looks at the block edge (d
 // steps) are only stored there. ck_at(n / CK) is where this lane's checkpoint goes.
 template <bool HOLE, int LANES, typename CkAt>
 __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t* rows, int lane, bool live, uint32_t tkey,
-                                        uint32_t pos0, uint32_t pos1, uint32_t lim, uint32_t& pos, uint32_t& n, int& s, CkAt ck_at) {
+                                        uint32_t pos0, uint32_t pos1, uint32_t lim, uint32_t& pos, uint32_t& n, int& s, CkAt ck_at,
+                                        const TileBlock* preloaded = nullptr) {
     TileBlock blk;
-    tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+    if (preloaded)
+        blk = *preloaded;   // the caller's block is centred on pos already
+    else
+        tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
     bool walking = live;
     int res = WR_LIMIT;
     const int maxbx = (tnx - 4) * 8, maxby = (tny - 4) * 8;
@@ -457,7 +461,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
         uint32_t pos = pos0, n = 0;
         // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
         int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, pos, n, s,
-                                     [&](uint32_t q) { return ck0 + q * 64 + lane; });
+                                     [&](uint32_t q) { return ck0 + q * 64 + lane; }, &blk);
         if (!live) res = WR_BAD;
         // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
         {
