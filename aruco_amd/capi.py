@@ -64,6 +64,7 @@ SYMBOLS = [
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
     "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
     "arucohip_debug_counters", "arucohip_board_detect_batch",
+    "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
 ]
 
 _lib = None
@@ -120,6 +121,10 @@ def load():
     L.arucohip_kernel_name.argtypes = [i]
     L.arucohip_debug_counters.argtypes = [vp, vp]
     L.arucohip_board_detect_batch.argtypes = [vp, i, vp, vp, i, i, vp, vp, i, f, f, i, vp, vp]
+    L.arucohip_gl_modelview.argtypes = [vp, vp, vp]
+    L.arucohip_ogre_pose.argtypes = [vp, vp, vp, vp]
+    L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
+    L.arucohip_ogre_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -345,3 +350,36 @@ class Handle:
                                                      int(bool(y_perp)), out, _ptr(prob)))
         return [{"n_markers": out[f].n_markers, "has_pose": out[f].has_pose, "rvec": np.array(out[f].rvec), "tvec": np.array(out[f].tvec),
                  "prob": float(prob[f])} for f in range(nframes)]
+
+
+# ---- OpenGL / Ogre conversions (host arithmetic)
+def gl_modelview(rvec, tvec):
+    """GetGLModelViewMatrix (src/utils.cpp:32-69): 16 doubles, column-major."""
+    L = load()
+    r, t, m = np.ascontiguousarray(rvec, np.float64), np.ascontiguousarray(tvec, np.float64), np.zeros(16, np.float64)
+    rc = L.arucohip_gl_modelview(_ptr(r), _ptr(t), _ptr(m))
+    if rc:
+        raise ArucoHipError(rc, "gl_modelview")
+    return m
+
+
+def ogre_pose(rvec, tvec):
+    """GetOgrePoseParameters (src/utils.cpp:71-147): (position[3], quaternion w,x,y,z)."""
+    L = load()
+    r, t = np.ascontiguousarray(rvec, np.float64), np.ascontiguousarray(tvec, np.float64)
+    pos, q = np.zeros(3, np.float64), np.zeros(4, np.float64)
+    rc = L.arucohip_ogre_pose(_ptr(r), _ptr(t), _ptr(pos), _ptr(q))
+    if rc:
+        raise ArucoHipError(rc, "ogre_pose")
+    return pos, q
+
+
+def gl_projection(K, cam_size, size, gnear, gfar, invert=False, ogre=False):
+    """CameraParameters::glGetProjectionMatrix / OgreGetProjectionMatrix (src/cameraparameters.cpp:226-295)."""
+    L = load()
+    Ka, m = np.ascontiguousarray(K, np.float32).reshape(-1), np.zeros(16, np.float64)
+    fn = L.arucohip_ogre_projection if ogre else L.arucohip_gl_projection
+    rc = fn(_ptr(Ka), int(cam_size[0]), int(cam_size[1]), int(size[0]), int(size[1]), float(gnear), float(gfar), int(bool(invert)), _ptr(m))
+    if rc:
+        raise ArucoHipError(rc, "gl_projection")
+    return m

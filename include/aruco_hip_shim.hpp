@@ -166,7 +166,35 @@ public:
         CameraMatrix(1, 1) *= AyFactor;
         CameraMatrix(1, 2) *= AyFactor;
     }
+    // cameraparameters.cpp:226-266 (like the reference it first resizes *this to `size`); orgImgSize is unused there too
+    void glGetProjectionMatrix(cv::Size /*orgImgSize*/, cv::Size size, double proj_matrix[16], double gnear, double gfar, bool invert = false) {
+        if (!isValid()) arucohip_throw_(ARUCOHIP_E_INVALID, "invalid camera parameters", nullptr);
+        float K[9];
+        for (int i = 0; i < 9; i++) K[i] = CameraMatrix(i / 3, i % 3);
+        arucohip_throw_(arucohip_gl_projection(K, CamSize.width, CamSize.height, size.width, size.height, gnear, gfar, invert, proj_matrix),
+                        "glGetProjectionMatrix", nullptr);
+        resize(size);   // the reference's call leaves the matrix resized (and CamSize as it was)
+    }
+    // cameraparameters.cpp:271-295
+    void OgreGetProjectionMatrix(cv::Size orgImgSize, cv::Size size, double proj_matrix[16], double gnear, double gfar, bool invert = false) {
+        double t[16];
+        glGetProjectionMatrix(orgImgSize, size, t, gnear, gfar, invert);
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) proj_matrix[r * 4 + c] = (c == 3 ? 1.0 : -1.0) * t[c * 4 + r];
+    }
 };
+
+// utils.cpp:32-147 behind the C ABI: shared by Marker and Board
+inline void arucohip_gl_modelview_(const cv::Mat_<double>& Rvec, const cv::Mat_<double>& Tvec, double modelview_matrix[16]) {
+    if (Rvec.empty() || Tvec.empty()) arucohip_throw_(ARUCOHIP_E_INVALID, "extrinsic parameters are not set", nullptr);
+    const double r[3] = {Rvec(0), Rvec(1), Rvec(2)}, t[3] = {Tvec(0), Tvec(1), Tvec(2)};
+    arucohip_throw_(arucohip_gl_modelview(r, t, modelview_matrix), "glGetModelViewMatrix", nullptr);
+}
+inline void arucohip_ogre_pose_(const cv::Mat_<double>& Rvec, const cv::Mat_<double>& Tvec, double position[3], double orientation[4]) {
+    if (Rvec.empty() || Tvec.empty()) arucohip_throw_(ARUCOHIP_E_INVALID, "extrinsic parameters are not set", nullptr);
+    const double r[3] = {Rvec(0), Rvec(1), Rvec(2)}, t[3] = {Tvec(0), Tvec(1), Tvec(2)};
+    arucohip_throw_(arucohip_ogre_pose(r, t, position, orientation), "OgreGetPoseParameters", nullptr);
+}
 
 class Marker : public std::vector<cv::Point2f> {
 public:
@@ -200,6 +228,8 @@ public:
         return (a2 + a1) / 2.f;
     }
     // marker.cpp:112-124 — needs a detector handle for the device solvePnP; see MarkerDetector::calculateExtrinsics
+    void glGetModelViewMatrix(double modelview_matrix[16]) const { arucohip_gl_modelview_(Rvec, Tvec, modelview_matrix); }              // marker.h:90
+    void OgreGetPoseParameters(double position[3], double orientation[4]) const { arucohip_ogre_pose_(Rvec, Tvec, position, orientation); }  // marker.h:104
     friend bool operator<(const Marker& a, const Marker& b) { return a.id < b.id; }
     friend std::ostream& operator<<(std::ostream& str, const Marker& M) {  // marker.h:128-139
         str << M.id << "=";
@@ -252,6 +282,8 @@ class Board : public std::vector<Marker> {
 public:
     BoardConfiguration conf;
     cv::Mat_<double> Rvec, Tvec;
+    void glGetModelViewMatrix(double modelview_matrix[16]) const { arucohip_gl_modelview_(Rvec, Tvec, modelview_matrix); }              // board.h:109
+    void OgreGetPoseParameters(double position[3], double orientation[4]) const { arucohip_ogre_pose_(Rvec, Tvec, position, orientation); }  // board.h:123
 };
 
 class MarkerDetector {

@@ -192,6 +192,21 @@ int arucohip_enable_timing(arucohip_handle* h, int on);
 int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap);
 const char* arucohip_kernel_name(int i);
 
+/* ---- OpenGL / Ogre conversions of the pose results (host arithmetic, no handle, no device work).
+ * GetGLModelViewMatrix (src/utils.cpp:32-69; Marker::glGetModelViewMatrix src/marker.h:90, Board:: src/board.h:109):
+ * column-major 4x4 from rvec / tvec (3 doubles each). */
+int arucohip_gl_modelview(const double* rvec, const double* tvec, double* modelview16);
+/* GetOgrePoseParameters (src/utils.cpp:71-147): position[3], orientation[4] = quaternion (w, x, y, z). */
+int arucohip_ogre_pose(const double* rvec, const double* tvec, double* position3, double* orientation4);
+/* CameraParameters::glGetProjectionMatrix (src/cameraparameters.cpp:226-266) including the CameraParameters::resize
+ * (:166-179) to width x height it starts with. K: 9 floats row-major, valid for cam_width x cam_height (= CamSize, which
+ * the reference keeps using for the right / bottom planes after the resize). */
+int arucohip_gl_projection(const float* K, int cam_width, int cam_height, int width, int height, double gnear, double gfar,
+                           int invert, double* proj16);
+/* CameraParameters::OgreGetProjectionMatrix (src/cameraparameters.cpp:271-295). */
+int arucohip_ogre_projection(const float* K, int cam_width, int cam_height, int width, int height, double gnear, double gfar,
+                             int invert, double* proj16);
+
 #ifdef __cplusplus
 }
 #endif
