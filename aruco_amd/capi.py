@@ -65,6 +65,7 @@ SYMBOLS = [
     "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
     "arucohip_debug_counters", "arucohip_board_detect_batch",
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
+    "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray",
 ]
 
 _lib = None
@@ -121,6 +122,9 @@ def load():
     L.arucohip_kernel_name.argtypes = [i]
     L.arucohip_debug_counters.argtypes = [vp, vp]
     L.arucohip_board_detect_batch.argtypes = [vp, i, vp, vp, i, i, vp, vp, i, f, f, i, vp, vp]
+    L.arucohip_detect_bgr.argtypes = [vp, vp, i, i, sz, vp, vp, i, f, i, vp, i, vp]
+    L.arucohip_detect_batch_bgr.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i]
+    L.arucohip_bgr_to_gray.argtypes = [vp, vp, i, i, sz, vp]
     L.arucohip_gl_modelview.argtypes = [vp, vp, vp]
     L.arucohip_ogre_pose.argtypes = [vp, vp, vp, vp]
     L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
@@ -204,6 +208,37 @@ class Handle:
         self._chk(self.L.arucohip_detect(self.h, _ptr(g), w, h, w, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
                                          float(marker_size), int(bool(y_perp)), _ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
+
+    def detect_bgr(self, bgr, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
+        """One host frame [H][W][3] in B,G,R order: converted to gray on the device, then detect()."""
+        b = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, c = b.shape
+        assert c == 3
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros(cap, MARKER_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_detect_bgr(self.h, _ptr(b), w, h, 3 * w, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                             float(marker_size), int(bool(y_perp)), _ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def detect_batch_bgr_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf, h, w, c = fr.shape
+        assert c == 3
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((nf, cap), MARKER_DTYPE)
+        n = np.zeros(nf, np.int32)
+        self._chk(self.L.arucohip_detect_batch_bgr(self.h, _ptr(fr), nf, w, h, 3 * w, 3 * w * h, 0, _ptr(Ka), _ptr(da),
+                                                   0 if da is None else da.size, float(marker_size), int(bool(y_perp)), _ptr(out), cap, _ptr(n), 0))
+        return [out[f, :n[f]].copy() for f in range(nf)]
+
+    def bgr_to_gray(self, bgr):
+        b = np.ascontiguousarray(bgr, dtype=np.uint8)
+        h, w, c = b.shape
+        assert c == 3
+        g = np.empty((h, w), np.uint8)
+        self._chk(self.L.arucohip_bgr_to_gray(self.h, _ptr(b), w, h, 3 * w, _ptr(g)))
+        return g
 
     def detect_batch_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
         fr = np.ascontiguousarray(frames, dtype=np.uint8)

@@ -38,8 +38,10 @@ struct arucohip_handle {
     arucohip_params_t params;
     arucohip_limits_t lim;
     Buffers buf{};
-    uint8_t* d_gray = nullptr;        // staging for host frames
+    uint8_t* d_gray = nullptr;        // staging for host frames (gray) and the converted BGR frames
     size_t gray_bytes = 0;
+    uint8_t* d_bgr = nullptr;         // staging for host BGR frames
+    size_t bgr_bytes = 0;
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
     size_t bits_bytes = 0;
     size_t patch_bytes = 0;           // capacity of buf.patches
@@ -162,7 +164,7 @@ static void free_all(arucohip_handle* h) {
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -579,21 +581,43 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     return ARUCOHIP_OK;
 }
 
+static int grow(arucohip_handle* h, uint8_t** buf, size_t* have, size_t need) {
+    if (need <= *have) return ARUCOHIP_OK;
+    if (*buf) HIPCHK(h, hipFree(*buf));
+    *buf = nullptr, *have = 0;
+    HIPCHK(h, hipMalloc((void**)buf, need));
+    *have = need;
+    return ARUCOHIP_OK;
+}
+
+// channels = 1: gray frames (device frames are used in place); channels = 3: B,G,R interleaved, converted into d_gray
 static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
-                        int on_device, const uint8_t** gray_dev, FrameGeom* g) {
+                        int on_device, int channels, const uint8_t** gray_dev, FrameGeom* g) {
     g->width = W, g->height = H;
+    int rc;
+    if (channels == 3) {
+        const uint8_t* bgr = frames;
+        size_t rs = row_stride, fs = frame_stride;
+        if (!on_device) {
+            if ((rc = grow(h, &h->d_bgr, &h->bgr_bytes, (size_t)nframes * W * H * 3))) return rc;
+            for (int f = 0; f < nframes; f++)
+                HIPCHK(h, hipMemcpy2DAsync(h->d_bgr + (size_t)f * W * H * 3, (size_t)W * 3, frames + (size_t)f * frame_stride, row_stride, (size_t)W * 3, H,
+                                           hipMemcpyHostToDevice, h->stream));
+            bgr = h->d_bgr, rs = (size_t)W * 3, fs = (size_t)W * H * 3;
+        }
+        if ((rc = grow(h, &h->d_gray, &h->gray_bytes, (size_t)nframes * W * H))) return rc;
+        launch_bgr2gray(h->stream, bgr, rs, fs, W, H, nframes, h->d_gray);
+        HIPCHK(h, hipGetLastError());
+        *gray_dev = h->d_gray;
+        g->row_stride = W, g->frame_stride = (size_t)W * H;
+        return ARUCOHIP_OK;
+    }
     if (on_device) {
         *gray_dev = frames;
         g->row_stride = row_stride, g->frame_stride = frame_stride;
         return ARUCOHIP_OK;
     }
-    size_t need = (size_t)nframes * W * H;
-    if (need > h->gray_bytes) {
-        if (h->d_gray) HIPCHK(h, hipFree(h->d_gray));
-        h->d_gray = nullptr, h->gray_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_gray, need));
-        h->gray_bytes = need;
-    }
+    if ((rc = grow(h, &h->d_gray, &h->gray_bytes, (size_t)nframes * W * H))) return rc;
     for (int f = 0; f < nframes; f++)
         HIPCHK(h, hipMemcpy2DAsync(h->d_gray + (size_t)f * W * H, W, frames + (size_t)f * frame_stride, row_stride, W, H,
                                    hipMemcpyHostToDevice, h->stream));
@@ -602,10 +626,10 @@ static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, 
     return ARUCOHIP_OK;
 }
 
-static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride) {
+static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride, int channels = 1) {
     if (nframes < 1 || nframes > h->lim.max_batch) return fail(h, ARUCOHIP_E_INVALID, "nframes outside 1..max_batch");
     if (W < 32 || H < 32 || (size_t)W * H > (size_t)h->lim.max_width * h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame larger than the handle was created for");
-    if (row_stride < (size_t)W) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width");
+    if (row_stride < (size_t)W * channels) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width * channels");
     return ARUCOHIP_OK;
 }
 
@@ -613,12 +637,12 @@ extern "C" {
 
 // enqueue one chunk on worker w (its buffers, its stream); results go to device memory or to w's pinned staging
 static int chunk_enqueue(arucohip_handle* w, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
-                         int frames_on_device, const DetectParams& dp, const CamModel& cam, arucohip_marker_t* out, int cap, int32_t* n_out,
+                         int frames_on_device, int channels, const DetectParams& dp, const CamModel& cam, arucohip_marker_t* out, int cap, int32_t* n_out,
                          int out_on_device) {
     int rc;
     const uint8_t* gray_dev;
     FrameGeom g;
-    if ((rc = stage_frames(w, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, &gray_dev, &g))) return rc;
+    if ((rc = stage_frames(w, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, channels, &gray_dev, &g))) return rc;
     if ((rc = detect_core(w, gray_dev, g, nframes, dp, cam))) return rc;
     const Buffers& b = w->buf;
     const int ncopy = std::min(cap, b.cap_markers);
@@ -668,11 +692,11 @@ static int join_workers(arucohip_handle* h, int chunks) {
     return ARUCOHIP_OK;
 }
 
-int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
-                          int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
-                          arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
+static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                             int frames_on_device, int channels, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                             arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
     if (!h || !frames || !n_out || (cap > 0 && !out) || cap < 0) return ARUCOHIP_E_INVALID;
-    int rc = check_geometry(h, nframes, W, H, row_stride);
+    int rc = check_geometry(h, nframes, W, H, row_stride, channels);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     DetectParams dp;
@@ -694,7 +718,7 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
         // streams on some boxes and hurts on others, hence off by default.
         static const bool chain = getenv("ARUCOHIP_CHAIN") && atoi(getenv("ARUCOHIP_CHAIN")) != 0;
         w->wait_thr = (chain && c > 0) ? (c == 1 ? h : h->kids[c - 2])->ev_thr : nullptr;
-        rc = chunk_enqueue(w, frames + (size_t)off * frame_stride, cnt, W, H, row_stride, frame_stride, frames_on_device, dp, cam,
+        rc = chunk_enqueue(w, frames + (size_t)off * frame_stride, cnt, W, H, row_stride, frame_stride, frames_on_device, channels, dp, cam,
                            out ? out + (size_t)off * cap : nullptr, cap, n_out + off, out_on_device);
         if (rc) {
             if (w != h) h->err = w->err;
@@ -712,6 +736,41 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
         if (ret == ARUCOHIP_OK) ret = r;
     }
     return ret;
+}
+
+int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                          int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                          arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
+    return detect_batch_impl(h, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, 1, K, dist, ndist, marker_size, y_perp, out, cap,
+                             n_out, out_on_device);
+}
+
+int arucohip_detect_batch_bgr(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                              int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                              arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
+    return detect_batch_impl(h, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, 3, K, dist, ndist, marker_size, y_perp, out, cap,
+                             n_out, out_on_device);
+}
+
+int arucohip_detect_bgr(arucohip_handle* h, const uint8_t* bgr, int W, int H, size_t row_stride, const float* K, const float* dist, int ndist,
+                        float marker_size, int y_perp, arucohip_marker_t* out, int cap, int* n_out) {
+    int32_t n = 0;
+    int rc = arucohip_detect_batch_bgr(h, bgr, 1, W, H, row_stride, (size_t)H * row_stride, 0, K, dist, ndist, marker_size, y_perp, out, cap, &n, 0);
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+int arucohip_bgr_to_gray(arucohip_handle* h, const uint8_t* bgr, int W, int H, size_t row_stride, uint8_t* gray) {
+    if (!h || !bgr || !gray) return ARUCOHIP_E_INVALID;
+    int rc = check_geometry(h, 1, W, H, row_stride, 3);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint8_t* dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, bgr, 1, W, H, row_stride, (size_t)H * row_stride, 0, 3, &dev, &g))) return rc;
+    HIPCHK(h, hipMemcpyAsync(gray, dev, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
 }
 
 int arucohip_batch_status(arucohip_handle* h) {
@@ -908,7 +967,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     if (rc) return rc;
     const uint8_t* gray_dev;
     FrameGeom g;
-    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &gray_dev, &g))) return rc;
+    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &gray_dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
@@ -936,7 +995,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     if (rc) return rc;
     const uint8_t* dev;
     FrameGeom g;
-    if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
+    if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
@@ -966,7 +1025,7 @@ int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t 
     HIPCHK(h, hipSetDevice(h->device));
     const uint8_t* dev;
     FrameGeom g;
-    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, &dev, &g))) return rc;
+    if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &dev, &g))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_small_f, quad, 8 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     launch_warp_only(h->stream, dev, g, h->d_small_f, size, h->d_patch);
     HIPCHK(h, hipGetLastError());

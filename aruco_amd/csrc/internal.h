@@ -135,6 +135,7 @@ struct Buffers {
 };
 
 // ---- kernel launchers (host side, defined in the .hip files)
+void launch_bgr2gray(hipStream_t s, const uint8_t* bgr, size_t row_stride, size_t frame_stride, int width, int height, int nframes, uint8_t* gray);
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);

@@ -299,16 +299,20 @@ public:
     // markerdetector.h:102-103
     void detect(const cv::Mat& input, std::vector<Marker>& detectedMarkers, cv::Mat camMatrix = cv::Mat(), cv::Mat distCoeff = cv::Mat(),
                 float markerSizeMeters = -1, bool setYPerpendicular = false) {
-        if (input.type() != CV_8UC1)
-            arucohip_throw_(ARUCOHIP_E_INVALID, "detect: the accelerated path takes 8-bit gray frames (convert BGR with the caller's cvtColor)", nullptr);
+        // markerdetector.cpp:303-310: 8-bit gray frames are used as they are, 3-channel frames are BGR and converted (on the device)
+        if (input.type() != CV_8UC1 && input.type() != CV_8UC3)
+            arucohip_throw_(ARUCOHIP_E_INVALID, "detect: 8-bit gray (CV_8UC1) or BGR (CV_8UC3) frames", nullptr);
         ensure_(input.cols, input.rows);
         float K[9], d[8];
         bool hasK = mat_to_K_(camMatrix, K);
         int nd = mat_to_dist_(distCoeff, d);
         std::vector<arucohip_marker_t> out(256);
         int n = 0;
-        int rc = arucohip_detect(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
-                                 setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n);
+        int rc = input.type() == CV_8UC3
+                     ? arucohip_detect_bgr(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
+                                           setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n)
+                     : arucohip_detect(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
+                                       setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n);
         arucohip_throw_(rc, "MarkerDetector::detect", h_);
         detectedMarkers.clear();
         for (int i = 0; i < n; i++) detectedMarkers.push_back(Marker::from_abi(out[i]));

@@ -129,6 +129,19 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
                           size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
                           float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
                           int out_on_device);
+/* SURVEY §8 row f3 — frames with three interleaved 8-bit channels in B,G,R order (what cv::imread / cv::VideoCapture
+ * deliver; row_stride >= 3*width): MarkerDetector::detect converts them with cv::cvtColor(CV_BGR2GRAY)
+ * (src/markerdetector.cpp:307-310); here the conversion runs on the device, bit-identical to OpenCV's 8-bit fixed-point
+ * form (B*1868 + G*9617 + R*4899 + 8192) >> 14, and the gray frames then take the path of arucohip_detect_batch. */
+int arucohip_detect_bgr(arucohip_handle* h, const uint8_t* bgr, int width, int height, size_t row_stride, const float* K,
+                        const float* dist, int ndist, float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap,
+                        int* n_out);
+int arucohip_detect_batch_bgr(arucohip_handle* h, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                              size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
+                              float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
+                              int out_on_device);
+/* The conversion alone: one host BGR frame -> host gray frame (width*height bytes). */
+int arucohip_bgr_to_gray(arucohip_handle* h, const uint8_t* bgr, int width, int height, size_t row_stride, uint8_t* gray);
 /* After an asynchronous batch: synchronise and report device-side overflow / capacity conditions. */
 int arucohip_batch_status(arucohip_handle* h);
 /* With the environment variable ARUCOHIP_STREAMS = 2..8 a large batch is processed as that many chunks of consecutive

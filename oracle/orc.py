@@ -205,6 +205,16 @@ def fiducial_detect(patch):
     return mid, nrot.value
 
 
+def bgr2gray(bgr):
+    """cv::cvtColor(BGR2GRAY) for 8-bit data (orc_imgproc.cpp; call site src/markerdetector.cpp:307-310)."""
+    b = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, c = b.shape
+    assert c == 3
+    g = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(b.ctypes.data_as(C.c_void_p), h * w, g.ctypes.data_as(C.c_void_p))
+    return g
+
+
 def solve_pnp(obj, img, K, dist):
     o, op = _f32(obj)
     m, mp = _f32(img)

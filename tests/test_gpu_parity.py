@@ -338,3 +338,24 @@ def test_4k_board_frames(env):
             assert rel_err(batched_f[f]["rvec"], of["rvec"]) < POSE_REL_TOL and rel_err(batched_f[f]["tvec"], of["tvec"]) < POSE_REL_TOL
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_bgr_input(env, handle):
+    """SURVEY §8 row f3: BGR frames are converted on the device exactly like cv::cvtColor(BGR2GRAY) (oracle restatement),
+    aligned and ragged widths; detection on a BGR frame equals detection on its gray conversion."""
+    orc = env["orc"]
+    rng = np.random.RandomState(21)
+    for (h, w) in ((64, 96), (75, 131), (480, 640)):
+        bgr = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        assert np.array_equal(handle.bgr_to_gray(bgr), orc.bgr2gray(bgr))
+    g, doc = load_case("single")
+    intr = doc["intrinsics"]
+    # a colour image whose gray conversion is NOT the plain channel: tint the channels, keep the result in range
+    bgr = np.stack([np.clip(g.astype(int) + 9, 0, 255), g.astype(int), np.clip(g.astype(int) - 7, 0, 255)], axis=2).astype(np.uint8)
+    gray = orc.bgr2gray(bgr)
+    a = handle.detect_bgr(bgr, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    b = handle.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    assert len(a) > 0 and a.tobytes() == b.tobytes()
+    batch = handle.detect_batch_bgr_host(np.stack([bgr, bgr[:, ::-1].copy()]), K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    assert batch[0].tobytes() == a.tobytes()

@@ -105,3 +105,14 @@ def test_synthetic_frame_detected_by_oracle():
     ms = orc.Oracle().detect(fr[0].numpy())
     ids = sorted(m["id"] for m in ms)
     assert ids == sorted(t["id"] for t in truth[0])
+
+
+def test_bgr2gray_matches_the_fixture_pipeline():
+    """Row f3: the oracle's cv::cvtColor(BGR2GRAY) restatement equals the 14-bit formula tests/golden/make_fixtures.py used
+    to turn the reference's PNGs into the committed gray rasters (whose detections match the reference's goldens)."""
+    rng = np.random.RandomState(11)
+    bgr = rng.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    exp = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(orc.bgr2gray(bgr), exp)
+    g = rng.randint(0, 256, size=(8, 9)).astype(np.uint8)
+    assert np.array_equal(orc.bgr2gray(np.repeat(g[..., None], 3, axis=2)), g)   # equal channels reproduce the value
