@@ -359,3 +359,53 @@ def test_bgr_input(env, handle):
     assert len(a) > 0 and a.tobytes() == b.tobytes()
     batch = handle.detect_batch_bgr_host(np.stack([bgr, bgr[:, ::-1].copy()]), K=intr["K"], dist=intr["dist"], marker_size=1.0)
     assert batch[0].tobytes() == a.tobytes()
+
+
+def test_segment_pipeline_mode(env, monkeypatch):
+    """ARUCOHIP_CONTOURS=segments (fully parallel waypoint-segment border extraction): same borders, same markers."""
+    capi = env["capi"]
+    monkeypatch.setenv("ARUCOHIP_CONTOURS", "segments")
+    h = capi.Handle(1920, 1080, max_batch=2)
+    monkeypatch.delenv("ARUCOHIP_CONTOURS")
+    ref = capi.Handle(1920, 1080, max_batch=2)
+    try:
+        rng = np.random.RandomState(7)
+        total = _contour_check(env, h, blob_image(rng, 240, 320, 6), True, 0.004, 1.0)
+        total += _contour_check(env, h, ((rng.rand(120, 160) > 0.55) * 255).astype(np.uint8), True, 0.002, 1.0)
+        assert total > 50
+        for name in ("single", "board"):
+            g, doc = load_case(name)
+            intr = doc["intrinsics"]
+            a = h.detect(g, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+            b = ref.detect(g, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+            assert len(a) > 0 and a.tobytes() == b.tobytes()
+    finally:
+        h.close()
+        ref.close()
+
+
+def test_chunk_streams(env, monkeypatch):
+    """ARUCOHIP_STREAMS=3: a batch cut into chunks on forked streams gives the bytes of the single-stream batch, and the
+    per-frame getters / batched board pose find their frame's worker."""
+    capi, synth = env["capi"], env["synth"]
+    fr, _ = synth.make_stream(7, seed=99, device="cuda")
+    frames = fr.cpu().numpy()
+    K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1]
+    monkeypatch.setenv("ARUCOHIP_STREAMS", "3")
+    h = capi.Handle(1920, 1080, max_batch=7)
+    monkeypatch.delenv("ARUCOHIP_STREAMS")
+    ref = capi.Handle(1920, 1080, max_batch=7)
+    try:
+        a = h.detect_batch_host(frames, K=K, dist=[0.0] * 5, marker_size=0.05)
+        b = ref.detect_batch_host(frames, K=K, dist=[0.0] * 5, marker_size=0.05)
+        assert h.batch_chunks() == (3, 3) and ref.batch_chunks()[0] == 1
+        for f in range(len(frames)):
+            assert len(a[f]) > 0 and a[f].tobytes() == b[f].tobytes()
+        for f in (0, 3, 6):   # one frame of every chunk
+            assert np.array_equal(h.thresholded(f, frames[f].shape), ref.thresholded(f, frames[f].shape))
+            ca, cb = h.debug_contours(f), ref.debug_contours(f)
+            assert len(ca) == len(cb) and all(np.array_equal(x["pts"], y["pts"]) for x, y in zip(ca, cb))
+        assert h.batch_status() == 0
+    finally:
+        h.close()
+        ref.close()
