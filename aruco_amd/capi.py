@@ -65,7 +65,7 @@ SYMBOLS = [
     "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
     "arucohip_debug_counters", "arucohip_board_detect_batch",
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
-    "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray",
+    "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray", "arucohip_set_dictionary",
 ]
 
 _lib = None
@@ -125,6 +125,7 @@ def load():
     L.arucohip_detect_bgr.argtypes = [vp, vp, i, i, sz, vp, vp, i, f, i, vp, i, vp]
     L.arucohip_detect_batch_bgr.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i]
     L.arucohip_bgr_to_gray.argtypes = [vp, vp, i, i, sz, vp]
+    L.arucohip_set_dictionary.argtypes = [vp, i, i, vp, i, f]
     L.arucohip_gl_modelview.argtypes = [vp, vp, vp]
     L.arucohip_ogre_pose.argtypes = [vp, vp, vp, vp]
     L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
@@ -208,6 +209,21 @@ class Handle:
         self._chk(self.L.arucohip_detect(self.h, _ptr(g), w, h, w, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
                                          float(marker_size), int(bool(y_perp)), _ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
+
+    def set_dictionary(self, markers, tau0, rate=1.0):
+        """HighlyReliableMarkers::loadDictionary: markers = bit strings of n*n characters; selects the HRM decoder
+        (None / empty list: back to the 5x5 fiducial decoder)."""
+        p = self.get_params()
+        if not markers:
+            p.decoder_kind = 0
+            self.set_params(p)
+            self._chk(self.L.arucohip_set_dictionary(self.h, 0, 0, None, 0, 1.0))
+            return
+        n = int(round(len(markers[0]) ** 0.5))
+        codes = np.array([sum(1 << i for i, ch in enumerate(m) if ch == "1") for m in markers], np.uint64)
+        self._chk(self.L.arucohip_set_dictionary(self.h, n, len(codes), _ptr(codes), int(tau0), float(rate)))
+        p.decoder_kind = 1
+        self.set_params(p)
 
     def detect_bgr(self, bgr, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
         """One host frame [H][W][3] in B,G,R order: converted to gray on the device, then detect()."""

@@ -42,6 +42,10 @@ struct arucohip_handle {
     size_t gray_bytes = 0;
     uint8_t* d_bgr = nullptr;         // staging for host BGR frames
     size_t bgr_bytes = 0;
+    // highly reliable markers (arucohip_set_dictionary)
+    uint64_t* d_hrm = nullptr;
+    int hrm_n = 0, hrm_count = 0, hrm_tau0 = 0;
+    float hrm_rate = 1.f;
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
     size_t bits_bytes = 0;
     size_t patch_bytes = 0;           // capacity of buf.patches
@@ -143,7 +147,7 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
     if (p->thres_method != ARUCOHIP_THRES_FIXED && p->thres_method != ARUCOHIP_THRES_ADPT) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
     if (p->corner_method < ARUCOHIP_CORNER_NONE || p->corner_method > ARUCOHIP_CORNER_LINES) return fail(h, ARUCOHIP_E_INVALID, "bad corner method");
     if (p->use_locked_corners) return fail(h, ARUCOHIP_E_UNSUPPORTED, "locked corners are not on the accelerated path");
-    if (p->decoder_kind != ARUCOHIP_DECODER_FIDUCIAL_5X5) return fail(h, ARUCOHIP_E_UNSUPPORTED, "only the 5x5 fiducial decoder runs on device");
+    if (p->decoder_kind != ARUCOHIP_DECODER_FIDUCIAL_5X5 && p->decoder_kind != ARUCOHIP_DECODER_HRM) return fail(h, ARUCOHIP_E_INVALID, "bad decoder kind");
     if (p->thres_param1_range < 0 || 2 * p->thres_param1_range + 1 > 16) return fail(h, ARUCOHIP_E_UNSUPPORTED, "threshold range too large");
     if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 > 15) return fail(h, ARUCOHIP_E_UNSUPPORTED, "SUBPIX window > 15");
     if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 < 1) return fail(h, ARUCOHIP_E_INVALID, "SUBPIX window < 1");
@@ -164,7 +168,7 @@ static void free_all(arucohip_handle* h) {
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_hrm), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -429,6 +433,13 @@ static int make_detect_params(arucohip_handle* h, int W, int H, DetectParams* dp
     dp->bx0 = std::min(x1, x2), dp->by0 = std::min(y1, y2);
     dp->bx1 = std::max(x1, x2), dp->by1 = std::max(y1, y2);
     dp->subpix_win = (int)p.thres_param1;
+    dp->decoder = p.decoder_kind;
+    if (p.decoder_kind == ARUCOHIP_DECODER_HRM) {
+        if (!h->d_hrm || h->hrm_count <= 0) return fail(h, ARUCOHIP_E_INVALID, "decoder HRM without a dictionary (arucohip_set_dictionary)");
+        if (p.warp_size < 2 * (h->hrm_n + 2)) return fail(h, ARUCOHIP_E_INVALID, "warp size too small for the dictionary's markers");
+        dp->hrm_n = h->hrm_n, dp->hrm_count = h->hrm_count, dp->hrm_codes = h->d_hrm;
+        dp->hrm_correction = (uint32_t)(h->hrm_rate * (float)((h->hrm_tau0 - 1) / 2));   // highlyreliablemarkers.cpp:318
+    }
     return ARUCOHIP_OK;
 }
 
@@ -770,6 +781,25 @@ int arucohip_bgr_to_gray(arucohip_handle* h, const uint8_t* bgr, int W, int H, s
     if ((rc = stage_frames(h, bgr, 1, W, H, row_stride, (size_t)H * row_stride, 0, 3, &dev, &g))) return rc;
     HIPCHK(h, hipMemcpyAsync(gray, dev, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t* codes, int tau0, float correction_rate) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_hrm) HIPCHK(h, hipFree(h->d_hrm));
+    h->d_hrm = nullptr, h->hrm_count = 0, h->hrm_n = 0;
+    if (count > 0) {
+        if (!codes || n < 2 || n > 5 || count > 4096) return fail(h, ARUCOHIP_E_UNSUPPORTED, "dictionary: 2 <= n <= 5, count <= 4096");
+        HIPCHK(h, hipMalloc((void**)&h->d_hrm, (size_t)count * sizeof(uint64_t)));
+        HIPCHK(h, hipMemcpy(h->d_hrm, codes, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice));
+        h->hrm_n = n, h->hrm_count = count, h->hrm_tau0 = tau0, h->hrm_rate = correction_rate;
+    }
+    for (auto* k : h->kids) {
+        int rc = arucohip_set_dictionary(k, n, count, codes, tau0, correction_rate);
+        if (rc) return rc;
+    }
     return ARUCOHIP_OK;
 }
 

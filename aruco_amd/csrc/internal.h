@@ -96,6 +96,11 @@ struct DetectParams {
     int min_contour, max_contour;   // contour length bounds (exclusive)
     int bx0, by0, bx1, by1;         // valid region of the border filter [bx0,bx1) x [by0,by1)
     int subpix_win;
+    // decoder: 0 = 5x5 fiducial, 1 = highly reliable markers with the handle's dictionary
+    int decoder;
+    int hrm_n, hrm_count;
+    uint32_t hrm_correction;        // largest Hamming distance that is still corrected
+    const uint64_t* hrm_codes;      // device
 };
 
 // device pointers + capacities handed to kernels

@@ -458,6 +458,70 @@ __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
     }
 }
 
+// 5d' — highly reliable markers: HighlyReliableMarkers::detect, src/highlyreliablemarkers.cpp:332-383.
+// One wavefront per candidate: lane = inner cell (n*n <= 25), majority vote on the Otsu-binarised patch, the code and its
+// three rotations (MarkerCode::set :113-142) through ballots, then the lanes share the dictionary: nearest entry over the
+// four rotations with the reference's first-minimum order (entries ascending, then rotations), accepted if its Hamming
+// distance is at most the correction distance; an exact match is the distance-0 case (the reference finds it through
+// 32-bit ids that are unique for n <= 5).
+struct HrmArgs {
+    int n, count;
+    uint32_t correction;
+    const uint64_t* codes;
+};
+
+__global__ __launch_bounds__(64) void hrm_decode_kernel(DecodeArgs a, HrmArgs d) {
+    const uint32_t ncand = min(a.counters[CNT_NCAND], a.cap_flat);
+    const int lane = threadIdx.x, n = d.n, nn = n * n;
+    for (uint32_t idx = blockIdx.x; idx < ncand; idx += gridDim.x) {
+        const uint32_t e = a.cand_list[idx];
+        Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
+        const int ws = a.ws, cell = ws / (n + 2), thr = a.othr[idx];
+        const uint8_t* patch = a.patches + (size_t)idx * ws * ws;
+        const int y = lane / n, x = lane - y * n;
+        bool white = false;
+        if (lane < nn) {   // getMarkerCode: inner cell (y, x) is white iff more than half of its pixels exceed the Otsu threshold
+            int cnt = 0;
+            for (int py = 0; py < cell; py++)
+                for (int px = 0; px < cell; px++) cnt += patch[((y + 1) * cell + py) * ws + (x + 1) * cell + px] > thr;
+            white = cnt > (cell * cell) / 2;
+        }
+        // rotation r puts cell (y, x) at (ry, rx): r=1 (x, n-y-1), r=2 (n-y-1, n-x-1), r=3 (n-x-1, y); a ballot needs the
+        // value at the destination lane, so every lane fetches the vote of its source cell
+        unsigned long long rot[4];
+        rot[0] = __ballot(white);
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            // destination (y, x) <- source (sy, sx): invert the mapping above
+            const int sy = r == 1 ? n - x - 1 : r == 2 ? n - y - 1 : x;
+            const int sx = r == 1 ? y : r == 2 ? n - x - 1 : n - y - 1;
+            const int srcl = lane < nn ? sy * n + sx : lane;
+            const int v = __shfl((int)white, srcl, 64);
+            rot[r] = __ballot(lane < nn && v != 0);
+        }
+        // nearest dictionary entry: key = distance << 16 | entry << 2 | rotation, smallest key wins (= first minimum)
+        uint32_t best = 0xFFFFFFFFu;
+        for (int i = lane; i < d.count; i += WAVE) {
+            const unsigned long long c = d.codes[i];
+            uint32_t dm = (uint32_t)nn, rm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t hd = (uint32_t)__popcll(c ^ rot[r]);
+                if (hd < dm) dm = hd, rm = (uint32_t)r;
+            }
+            if (dm < (uint32_t)nn) best = min(best, (dm << 16) | ((uint32_t)i << 2) | rm);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+        if (lane == 0) {
+            int id = -1, nrot = 0;
+            if (best != 0xFFFFFFFFu && (best >> 16) <= d.correction) id = (int)((best >> 2) & 0x3FFFu), nrot = (int)(best & 3u);
+            cand->id = id;
+            cand->nrot = nrot;
+        }
+    }
+}
+
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     DecodeArgs a;
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride, a.width = g.width, a.height = g.height;
@@ -468,7 +532,12 @@ void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int n
     hipLaunchKernelGGL(homography_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
     hipLaunchKernelGGL(warp_hist_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
     hipLaunchKernelGGL(otsu_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(cells_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
+    if (p.decoder == 1) {
+        HrmArgs d{p.hrm_n, p.hrm_count, p.hrm_correction, p.hrm_codes};
+        hipLaunchKernelGGL(hrm_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a, d);
+    } else {
+        hipLaunchKernelGGL(cells_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
+    }
 }
 
 // MarkerDetector::warp as a stage entry point: one patch from one quad

@@ -41,7 +41,7 @@ enum { ARUCOHIP_CORNER_NONE = 0, ARUCOHIP_CORNER_HARRIS = 1, ARUCOHIP_CORNER_SUB
 /* BoardConfiguration::mInfoType (board.h:64) */
 enum { ARUCOHIP_BOARD_NONE = -1, ARUCOHIP_BOARD_PIX = 0, ARUCOHIP_BOARD_METERS = 1 };
 /* decoder behind MarkerDetector::setMakerDetectorFunction (markerdetector.h:243) */
-enum { ARUCOHIP_DECODER_FIDUCIAL_5X5 = 0 };
+enum { ARUCOHIP_DECODER_FIDUCIAL_5X5 = 0, ARUCOHIP_DECODER_HRM = 1 };
 
 /* 1:1 image of MarkerDetector's private configuration members (markerdetector.h:283-306; defaults .cpp:235-249). */
 typedef struct arucohip_params {
@@ -55,7 +55,7 @@ typedef struct arucohip_params {
     float max_size;             /* _maxSize            default 0.5  */
     float border_dist;          /* _borderDistThres    default 0.025 */
     int32_t use_locked_corners; /* _useLockedCorners   default 0 (1 -> ARUCOHIP_E_UNSUPPORTED) */
-    int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5 */
+    int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5, or ARUCOHIP_DECODER_HRM after arucohip_set_dictionary */
     int32_t reserved_;
 } arucohip_params_t;
 
@@ -129,6 +129,15 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
                           size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
                           float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
                           int out_on_device);
+/* SURVEY §8 row f1 — highly reliable markers: HighlyReliableMarkers::loadDictionary (src/highlyreliablemarkers.cpp:311-329).
+ * codes[i] = marker i of the dictionary as n*n bits, bit y*n+x = cell (y, x) ('1' in aruco::Dictionary's bit strings),
+ * n <= 5 (the reference's 32-bit marker ids are unique up to there), count <= 4096; tau0 = Dictionary::tau0,
+ * correction_rate = correctionDistanceRate (the reference's default is 1). With params.decoder_kind = ARUCOHIP_DECODER_HRM
+ * the candidates are then decoded like HighlyReliableMarkers::detect (:332-383) — id = position in the dictionary — which
+ * is what MarkerDetector::setMakerDetectorFunction(HighlyReliableMarkers::detect) selects in the reference; the warp size
+ * should be a multiple of n + 2 (the reference's apps use (n + 2) * 8). count = 0 drops the dictionary. */
+int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t* codes, int tau0, float correction_rate);
+
 /* SURVEY §8 row f3 — frames with three interleaved 8-bit channels in B,G,R order (what cv::imread / cv::VideoCapture
  * deliver; row_stride >= 3*width): MarkerDetector::detect converts them with cv::cvtColor(CV_BGR2GRAY)
  * (src/markerdetector.cpp:307-310); here the conversion runs on the device, bit-identical to OpenCV's 8-bit fixed-point

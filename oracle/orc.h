@@ -96,9 +96,18 @@ bool solve_pnp_iterative(const Pt3f* obj, const Pt2f* img, int n, const float K[
                          double rvec[3], double tvec[3]);
 void rotate_x_axis(double rvec[3]);
 
+// Dictionary of highly reliable markers (aruco::Dictionary, src/highlyreliablemarkers.h:170-190): n x n codes, bit y*n+x of
+// codes[i] = cell (y, x) of marker i in rotation 0.
+struct HrmDict {
+    int n = 0, tau0 = 0;
+    float rate = 1.f;                 // correctionDistanceRate of HighlyReliableMarkers::loadDictionary
+    std::vector<uint64_t> codes;
+};
+
 // ---- detection pipeline (orc_detect.cpp)
 struct Detector {
     Params prm;
+    HrmDict hrm;                                // hrm.n > 0: markerIdDetectorFunc = HighlyReliableMarkers::detect
     // results retained like the reference's members
     std::vector<uint8_t> thres;                 // getThresholdedImage()
     std::vector<Candidate> rejected;            // getCandidates()
@@ -112,6 +121,7 @@ struct Detector {
 };
 int fiducial_decode(const uint8_t* patch, int size, int* nrot);  // patch is Otsu-binarised in place by the caller
 int fiducial_detect(uint8_t* patch, int size, int* nrot);
+int hrm_detect(uint8_t* patch, int size, const HrmDict& d, int* nrot);
 void refine_lines(Candidate& cand, const float* K, const float* dist, int ndist);
 void corner_subpix(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n, int win, int max_iter, double eps);
 void corner_harris_refine(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n);

@@ -90,6 +90,14 @@ class Oracle:
             setattr(p, k, v)
         self.L.orc_set_params(self.h, C.byref(p))
 
+    def set_hrm_dictionary(self, markers, tau0, rate=1.0):
+        """HighlyReliableMarkers::loadDictionary + setMakerDetectorFunction(HighlyReliableMarkers::detect).
+        markers: bit strings of n*n characters (row-major, '1' = white); None / empty restores the fiducial decoder."""
+        codes = hrm_codes(markers or [])
+        n = int(round(len(markers[0]) ** 0.5)) if markers else 0
+        arr = (C.c_uint64 * max(len(codes), 1))(*codes)
+        self.L.orc_set_hrm(self.h, n, len(codes), arr, int(tau0), C.c_float(rate))
+
     def detect(self, gray, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=256):
         g, gp = _u8(gray)
         h, w = g.shape
@@ -203,6 +211,11 @@ def fiducial_detect(patch):
     nrot = C.c_int(0)
     mid = lib().orc_fiducial_detect(pp, p.shape[0], C.byref(nrot))
     return mid, nrot.value
+
+
+def hrm_codes(markers):
+    """Dictionary bit strings -> uint64 codes, bit y*n+x = cell (y, x)."""
+    return [sum(1 << i for i, ch in enumerate(m) if ch == "1") for m in markers]
 
 
 def bgr2gray(bgr):

@@ -48,6 +48,12 @@ static Marker from_c(const orc_marker_t& o) {
 }
 
 void* orc_create() { return new Detector(); }
+// HighlyReliableMarkers::loadDictionary + setMakerDetectorFunction(HighlyReliableMarkers::detect); count = 0 restores the fiducial decoder
+void orc_set_hrm(void* h, int n, int count, const uint64_t* codes, int tau0, float rate) {
+    HrmDict& d = ((Detector*)h)->hrm;
+    d.n = count > 0 ? n : 0, d.tau0 = tau0, d.rate = rate;
+    d.codes.assign(codes, codes + (count > 0 ? count : 0));
+}
 void orc_destroy(void* h) { delete (Detector*)h; }
 
 void orc_get_params(void* h, orc_params_t* p) {

@@ -87,6 +87,43 @@ int fiducial_detect(uint8_t* patch, int size, int* nrot) {
     return fiducial_decode(patch, size, nrot);
 }
 
+// HighlyReliableMarkers::detect (src/highlyreliablemarkers.cpp:332-383): Otsu binarisation, inner n x n cells by majority
+// (getMarkerCode, src/arucofidmarkers.cpp:189-204; the border cells are not checked), the code in its four rotations
+// (MarkerCode::set :113-142), then the dictionary entry that equals one of the rotations (first rotation that matches,
+// BalancedBinaryTree::findId :505-518) or, failing that, the nearest entry within the correction distance
+// (Dictionary::distance :262-274 with MarkerCode::distance :160-170: first minimum over entries, then over rotations).
+// Returns the entry's position in the dictionary. The reference looks exact matches up through 32-bit ids (2 << bit
+// position, :137-138), which are unique for n <= 5; with unique ids an exact match is the distance-0 case of the
+// nearest-entry search with the same first-minimum order, which is what is restated here.
+int hrm_detect(uint8_t* patch, int size, const HrmDict& d, int* nrot) {
+    *nrot = 0;
+    const int n = d.n;
+    if (n <= 0 || n * n > 64 || d.codes.empty()) return -1;
+    int t = otsu_threshold(patch, size * size);
+    for (int i = 0; i < size * size; i++) patch[i] = patch[i] > t ? 255 : 0;
+    const int cell = size / (n + 2);
+    uint64_t rot[4] = {0, 0, 0, 0};
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            if (!(count_nonzero(patch, size, (x + 1) * cell, (y + 1) * cell, cell) > (cell * cell) / 2)) continue;
+            const int ry[4] = {y, x, n - y - 1, n - x - 1}, rx[4] = {x, n - y - 1, n - x - 1, y};
+            for (int r = 0; r < 4; r++) rot[r] |= 1ull << (ry[r] * n + rx[r]);
+        }
+    unsigned best = (unsigned)(n * n), best_marker = 0, best_rot = 0;
+    for (size_t i = 0; i < d.codes.size(); i++) {
+        unsigned dm = (unsigned)(n * n), rm = 0;
+        for (unsigned r = 0; r < 4; r++) {
+            unsigned h = (unsigned)__builtin_popcountll(d.codes[i] ^ rot[r]);
+            if (h < dm) dm = h, rm = r;
+        }
+        if (dm < best) best = dm, best_marker = (unsigned)i, best_rot = rm;
+    }
+    const unsigned correction = (unsigned)(d.rate * (float)((d.tau0 - 1) / 2));   // loadDictionary :318
+    if (best == (unsigned)(n * n) || best > correction) return -1;
+    *nrot = (int)best_rot;
+    return (int)best_marker;
+}
+
 // ---------------------------------------------------------------------------------------------
 // detectRectangles (src/markerdetector.cpp:496-635)
 // ---------------------------------------------------------------------------------------------
@@ -388,7 +425,7 @@ int Detector::detect(const uint8_t* gray, int W, int H, int stride, const float*
         double M[9];
         perspective_transform(c.c, dst, M);
         warp_perspective_nearest(gray, W, H, stride, M, ws, patch.data());
-        c.id = fiducial_detect(patch.data(), ws, &c.nrot);
+        c.id = hrm.n > 0 ? hrm_detect(patch.data(), ws, hrm, &c.nrot) : fiducial_detect(patch.data(), ws, &c.nrot);
         if (c.id != -1) {
             if (prm.corner_method == 3) refine_lines(c, K, dist, ndist);
             std::rotate(c.c, c.c + 4 - c.nrot, c.c + 4);

@@ -11,6 +11,9 @@ Run in the build container only (needs /root/reference/testdata). Outputs are da
                         (src/cameraparameters.cpp:203-219: K -> f32, first 5 dist coeffs -> f32)
                         and the board configuration (board_pix.yml / chessboardinfo_pix.yml).
   * board_gl.json       testdata/board/expected_gl.yml (GL matrices; pins per-marker poses).
+  * hrm.pgm / hrm.json  testdata/hrm (highly reliable markers, test/core_tests.cpp:310-353): frame, expected markers,
+                        intrinsics (resized to the frame like the test does), the 4x4 dictionary d4x4_100.yml
+                        (marker bit strings, tau0) and the detector settings the test applies.
 No reference source text is copied; only test inputs and expected outputs.
 """
 import json
@@ -107,6 +110,20 @@ def main():
             doc["board_conf"] = board_conf(os.path.join(REF, bc))
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(doc, f, indent=1)
+    # highly reliable markers
+    rgb = np.asarray(Image.open(os.path.join(REF, "hrm/image-test.png")).convert("RGB"))
+    write_pgm(os.path.join(OUT, "hrm.pgm"), bgr2gray_cv3(rgb))
+    y = load_cv_yaml(os.path.join(REF, "hrm/expected.yml"))
+    d = load_cv_yaml(os.path.join(REF, "hrm/dictionaries/d4x4_100.yml"))
+    doc = {"source_png": "hrm/image-test.png", "intrinsics": intrinsics(os.path.join(REF, "hrm/intrinsics.yml")),
+           "markers": markers(y["Markers"]),
+           "dictionary": {"n": int(d["markersize"]), "tau0": int(d["tau0"]),
+                          "markers": [str(d["marker_%d" % i]).zfill(int(d["markersize"]) ** 2) for i in range(int(d["nmarkers"]))]},
+           # test/core_tests.cpp:324-329
+           "settings": {"thres_param1": 21, "thres_param2": 7, "corner_method": "LINES", "min_size": 0.005, "max_size": 0.5,
+                        "warp_size": (int(d["markersize"]) + 2) * 8, "marker_size": 1.0}}
+    with open(os.path.join(OUT, "hrm.json"), "w") as f:
+        json.dump(doc, f, indent=1)
     gl = load_cv_yaml(os.path.join(REF, "board/expected_gl.yml"))
     with open(os.path.join(OUT, "board_gl.json"), "w") as f:
         json.dump({"gldata": [[float(v) for v in row] for row in gl["gldata"]]}, f, indent=1)

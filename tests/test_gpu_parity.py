@@ -409,3 +409,46 @@ def test_chunk_streams(env, monkeypatch):
     finally:
         h.close()
         ref.close()
+
+
+def test_hrm_decoder(env):
+    """highly reliable markers (reference test Aruco.HRM_Single, test/core_tests.cpp:310-353) through
+    the HIP path: dictionary d4x4_100, the test's detector settings; equals the CPU restatement and the reference's golden."""
+    capi, orc = env["capi"], env["orc"]
+    gray, doc = load_case("hrm")
+    intr, st, dic = doc["intrinsics"], doc["settings"], doc["dictionary"]
+    h = capi.Handle(640, 480, max_batch=2)
+    try:
+        p = h.get_params()
+        p.thres_param1, p.thres_param2, p.min_size, p.max_size, p.warp_size = st["thres_param1"], st["thres_param2"], st["min_size"], st["max_size"], st["warp_size"]
+        h.set_params(p)
+        h.set_dictionary(dic["markers"], dic["tau0"])
+        got = h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=st["marker_size"])
+        o = orc.Oracle(thres_p1=st["thres_param1"], thres_p2=st["thres_param2"], min_size=st["min_size"], max_size=st["max_size"],
+                       warp_size=st["warp_size"])
+        o.set_hrm_dictionary(dic["markers"], dic["tau0"])
+        ref = o.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=st["marker_size"])
+        _compare_markers(got, ref, pose=True)
+        assert [int(m["id"]) for m in got] == [e["id"] for e in doc["markers"]]
+        for m, e in zip(got, doc["markers"]):
+            assert rel_err(m["rvec"], e["Rvec"]) < POSE_REL_TOL and rel_err(m["tvec"], e["Tvec"]) < POSE_REL_TOL
+        # every candidate's decode result (id and rotation), not only the accepted markers
+        dq, did, drot = h.debug_candidates(0)
+        cands = o.candidates()
+        assert [int(v) for v in did] == [c["id"] for c in cands]
+        assert all(int(a) == c["nrot"] for a, c in zip(drot, cands) if c["id"] >= 0)
+        # a rotated frame exercises the other rotations; a corrupted dictionary entry exercises the error correction
+        got90 = h.detect(np.ascontiguousarray(np.rot90(gray)), marker_size=-1.0)
+        ref90 = o.detect(np.ascontiguousarray(np.rot90(gray)))
+        _compare_markers(got90, ref90)
+        bad = list(dic["markers"])
+        bad[3] = ("0" if bad[3][0] == "1" else "1") + bad[3][1:]          # one wrong bit: still within (tau0-1)/2 = 1
+        h.set_dictionary(bad, dic["tau0"])
+        o.set_hrm_dictionary(bad, dic["tau0"])
+        _compare_markers(h.detect(gray), o.detect(gray))
+        assert 3 in [int(m["id"]) for m in h.detect(gray)]
+        h.set_dictionary(None, 0)                                           # back to the fiducial decoder
+        o.set_hrm_dictionary(None, 0)
+        _compare_markers(h.detect(gray), o.detect(gray))
+    finally:
+        h.close()

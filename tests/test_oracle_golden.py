@@ -67,3 +67,20 @@ def test_board_pnp_only():
         b = orc.board_detect(ms, bc["ids"], bc["obj"], bc["info_type"], intr["K"], intr["dist"], 1.0)
         assert rel_err(b["rvec"], doc["board"]["Rvec"]) < 1e-6
         assert rel_err(b["tvec"], doc["board"]["Tvec"]) < 1e-6
+
+
+def test_hrm_golden():
+    """Reference test Aruco.HRM_Single (test/core_tests.cpp:310-353): highly reliable markers, dictionary d4x4_100, the
+    detector settings of the test, per-marker poses. ids exact; the test itself only compares ids, centres and poses."""
+    gray, doc = load_case("hrm")
+    intr, st, dic = doc["intrinsics"], doc["settings"], doc["dictionary"]
+    o = orc.Oracle(thres_p1=st["thres_param1"], thres_p2=st["thres_param2"], min_size=st["min_size"], max_size=st["max_size"],
+                   warp_size=st["warp_size"])
+    o.set_hrm_dictionary(dic["markers"], dic["tau0"])
+    ms = o.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=st["marker_size"])
+    exp = doc["markers"]
+    assert [m["id"] for m in ms] == [e["id"] for e in exp]
+    for m, e in zip(ms, exp):
+        assert np.max(np.abs(m["corners"] - np.array(e["corners"]))) < CORNER_ABS_TOL
+        assert rel_err(m["rvec"], e["Rvec"]) < POSE_REL_TOL
+        assert rel_err(m["tvec"], e["Tvec"]) < POSE_REL_TOL
