@@ -20,6 +20,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <fstream>
 #include <vector>
 
 #include "arucohip.h"
@@ -286,6 +287,97 @@ public:
     void OgreGetPoseParameters(double position[3], double orientation[4]) const { arucohip_ogre_pose_(Rvec, Tvec, position, orientation); }  // board.h:123
 };
 
+// ---- marker-id decoders (markerdetector.h:248 setMakerDetectorFunction). On the accelerated path the decoders run on the
+// device; the static functions below are the tokens a caller passes to MarkerDetector::setMakerDetectorFunction.
+class FiducidalMarkers {
+public:
+    // arucofidmarkers.h:84 — the default decoder (5x5 Hamming markers)
+    static int detect(const cv::Mat&, int&) {
+        arucohip_throw_(ARUCOHIP_E_UNSUPPORTED, "FiducidalMarkers::detect runs on the device; pass it to setMakerDetectorFunction", nullptr);
+        return -1;
+    }
+};
+
+// highlyreliablemarkers.h:50-140 (the part the detection path needs: size and bits)
+class MarkerCode {
+public:
+    explicit MarkerCode(unsigned int n = 0) : _n(n), _bits(n * n, '0') {}
+    void fromString(const std::string& s) { _bits = s; }
+    std::string toString() const { return _bits; }
+    unsigned int n() const { return _n; }
+    unsigned int size() const { return _n * _n; }
+    bool get(unsigned int pos) const { return _bits[pos] == '1'; }
+
+private:
+    unsigned int _n;
+    std::string _bits;
+};
+
+// highlyreliablemarkers.h:170-190; fromFile reads the reference's dictionary files (src/serialization.cpp:123-150:
+// nmarkers, markersize, tau0, marker_<i>: "<n*n bits>")
+class Dictionary : public std::vector<MarkerCode> {
+public:
+    int tau0 = 0;
+    bool fromFile(const std::string& filename) {
+        std::ifstream f(filename.c_str());
+        if (!f) arucohip_throw_(ARUCOHIP_E_INVALID, "Dictionary::fromFile: cannot open file", nullptr);
+        clear();
+        unsigned int n = 0;
+        size_t nmarkers = 0;
+        std::vector<std::pair<size_t, std::string> > codes;
+        std::string line;
+        while (std::getline(f, line)) {
+            size_t c = line.find(':');
+            if (c == std::string::npos || line[0] == '%') continue;
+            std::string key = line.substr(0, c), val = line.substr(c + 1);
+            key.erase(0, key.find_first_not_of(" \t"));
+            val.erase(0, val.find_first_not_of(" \t\""));
+            val.erase(val.find_last_not_of(" \t\"\r") + 1);
+            if (key == "nmarkers") nmarkers = (size_t)std::atol(val.c_str());
+            else if (key == "markersize") n = (unsigned int)std::atol(val.c_str());
+            else if (key == "tau0") tau0 = std::atoi(val.c_str());
+            else if (key.compare(0, 7, "marker_") == 0) codes.push_back(std::make_pair((size_t)std::atol(key.c_str() + 7), val));
+        }
+        if (n == 0 || codes.size() != nmarkers) arucohip_throw_(ARUCOHIP_E_INVALID, "Dictionary::fromFile: malformed dictionary", nullptr);
+        resize(nmarkers, MarkerCode(n));
+        for (size_t i = 0; i < codes.size(); i++) {
+            if (codes[i].first >= nmarkers || codes[i].second.size() != (size_t)n * n)
+                arucohip_throw_(ARUCOHIP_E_INVALID, "Dictionary::fromFile: malformed marker", nullptr);
+            (*this)[codes[i].first].fromString(codes[i].second);
+        }
+        return true;
+    }
+};
+
+// highlyreliablemarkers.h:196-260: static dictionary + decoder token
+class HighlyReliableMarkers {
+public:
+    static bool loadDictionary(Dictionary D, float correctionDistanceRate = 1) {  // highlyreliablemarkers.cpp:311-322
+        if (D.size() == 0) return false;
+        State_& s = state_();
+        s.D = D, s.rate = correctionDistanceRate, s.version++;
+        return true;
+    }
+    static bool loadDictionary(const std::string& filename, float correctionDistance = 1) {
+        Dictionary D;
+        D.fromFile(filename);
+        return loadDictionary(D, correctionDistance);
+    }
+    static int detect(const cv::Mat&, int&) {
+        arucohip_throw_(ARUCOHIP_E_UNSUPPORTED, "HighlyReliableMarkers::detect runs on the device; pass it to setMakerDetectorFunction", nullptr);
+        return -1;
+    }
+    struct State_ {
+        Dictionary D;
+        float rate = 1;
+        int version = 0;
+    };
+    static State_& state_() {
+        static State_ s;
+        return s;
+    }
+};
+
 class MarkerDetector {
 public:
     enum ThresholdMethods { FIXED_THRES, ADPT_THRES, CANNY };
@@ -303,6 +395,7 @@ public:
         if (input.type() != CV_8UC1 && input.type() != CV_8UC3)
             arucohip_throw_(ARUCOHIP_E_INVALID, "detect: 8-bit gray (CV_8UC1) or BGR (CV_8UC3) frames", nullptr);
         ensure_(input.cols, input.rows);
+        if (hrm_ && hrm_version_ != HighlyReliableMarkers::state_().version) apply_decoder_();
         float K[9], d[8];
         bool hasK = mat_to_K_(camMatrix, K);
         int nd = mat_to_dist_(distCoeff, d);
@@ -325,6 +418,18 @@ public:
         detect(input, detectedMarkers, camParams.CameraMatrix, camParams.Distorsion, markerSizeMeters, setYPerpendicular);
     }
 
+    // markerdetector.h:248: the two decoders of the library are accepted (they run on the device), other functions are not
+    void setMakerDetectorFunction(int (*markerdetector_func)(const cv::Mat& in, int& nRotations)) {
+        if (markerdetector_func == &HighlyReliableMarkers::detect)
+            hrm_ = true;
+        else if (markerdetector_func == &FiducidalMarkers::detect)
+            hrm_ = false;
+        else
+            arucohip_throw_(ARUCOHIP_E_UNSUPPORTED, "setMakerDetectorFunction: only FiducidalMarkers::detect and HighlyReliableMarkers::detect", nullptr);
+        p_.decoder_kind = hrm_ ? ARUCOHIP_DECODER_HRM : ARUCOHIP_DECODER_FIDUCIAL_5X5;   // part of the parameter set from now on
+        hrm_version_ = -1;
+        if (h_) apply_decoder_();
+    }
     void setThresholdMethod(ThresholdMethods m) { p_.thres_method = (int)m, push_(); }
     ThresholdMethods getThresholdMethod() const { return (ThresholdMethods)p_.thres_method; }
     void setThresholdParams(double param1, double param2) { p_.thres_param1 = param1, p_.thres_param2 = param2, push_(); }
@@ -449,11 +554,29 @@ private:
         h_ = nullptr;
         arucohip_throw_(arucohip_create(&p_, device_, w, hh, 1, &h_), "arucohip_create", nullptr);
         cap_w_ = w, cap_h_ = hh;
+        hrm_version_ = -1;
+        if (hrm_) apply_decoder_();
+    }
+    // HighlyReliableMarkers' static dictionary -> the handle (arucohip_set_dictionary), or back to the fiducial decoder
+    void apply_decoder_() {
+        if (hrm_) {
+            const HighlyReliableMarkers::State_& s = HighlyReliableMarkers::state_();
+            if (s.D.empty()) arucohip_throw_(ARUCOHIP_E_INVALID, "HighlyReliableMarkers: no dictionary loaded", nullptr);
+            std::vector<uint64_t> codes(s.D.size(), 0);
+            for (size_t i = 0; i < s.D.size(); i++)
+                for (unsigned int b = 0; b < s.D[i].size(); b++)
+                    if (s.D[i].get(b)) codes[i] |= 1ull << b;
+            arucohip_throw_(arucohip_set_dictionary(h_, (int)s.D[0].n(), (int)codes.size(), codes.data(), s.D.tau0, s.rate), "loadDictionary", h_);
+            hrm_version_ = s.version;
+        }
+        push_();
     }
     arucohip_handle* h_;
     int device_, cap_w_, cap_h_;
     arucohip_params_t p_;
     int speed_ = 0;
+    bool hrm_ = false;
+    int hrm_version_ = -1;
     cv::Size frame_size_;
     cv::Mat thres_;
     bool thres_valid_ = false, cand_valid_ = false;

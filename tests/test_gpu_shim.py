@@ -79,3 +79,31 @@ def test_aruco_simple_board(exe, tmp_path):
     assert m and abs(float(m.group(1)) - 1.0) < 1e-6
     assert rel_err([float(m.group(i)) for i in (2, 3, 4)], doc["board"]["Rvec"]) < 1e-4
     assert rel_err([float(m.group(i)) for i in (5, 6, 7)], doc["board"]["Tvec"]) < 1e-4
+
+
+def test_shim_hrm(tmp_path):
+    """Row f1 through the shim: Dictionary::fromFile on a file in the reference's format, HighlyReliableMarkers::
+    loadDictionary, MarkerDetector::setMakerDetectorFunction(HighlyReliableMarkers::detect) — the calls of the reference's
+    HRM_Single test — reproduce testdata/hrm/expected.yml."""
+    from aruco_amd import build_library
+    build_library()
+    doc = json.load(open(os.path.join(GOLDEN, "hrm.json")))
+    dic = doc["dictionary"]
+    with open(tmp_path / "dict.yml", "w") as f:
+        f.write("%%YAML:1.0\nnmarkers: %d\nmarkersize: %d\ntau0: %d\n" % (len(dic["markers"]), dic["n"], dic["tau0"]))
+        for i, m in enumerate(dic["markers"]):
+            f.write('marker_%d: "%s"\n' % (i, m))
+    intr = tmp_path / "intr.txt"
+    write_intrinsics(intr, doc["intrinsics"])
+    exe = tmp_path / "shim_hrm"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_hrm.cpp"), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), os.path.join(GOLDEN, "hrm.pgm"), str(tmp_path / "dict.yml"), str(intr)], stdout=subprocess.PIPE, text=True, check=True)
+    got = parse_markers(r.stdout)
+    exp = doc["markers"]
+    assert [g["id"] for g in got] == [e["id"] for e in exp]
+    for g, e in zip(got, exp):
+        assert np.max(np.abs(g["corners"] - np.array(e["corners"]))) < 1e-3
+        assert rel_err(g["rvec"], e["Rvec"]) < 1e-4 and rel_err(g["tvec"], e["Tvec"]) < 1e-4
+    assert "fiducial=" in r.stdout
