@@ -20,6 +20,8 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <cstdlib>
+#include <iterator>
 #include <fstream>
 #include <vector>
 
@@ -141,6 +143,58 @@ inline int mat_to_dist_(const cv::Mat& m, float d[8]) {
     return n;
 }
 
+// ---- minimal reader for the OpenCV FileStorage YAML files the reference ships and writes (camera intrinsics
+// src/cameraparameters.cpp:187-222, board configurations src/serialization.cpp:94-120): top-level scalars, !!opencv-matrix
+// blocks and the flow-style marker list. Not a general YAML parser.
+namespace yml_ {
+inline std::string slurp(const std::string& path) {
+    std::ifstream f(path.c_str());
+    if (!f) arucohip_throw_(ARUCOHIP_E_INVALID, ("cannot open " + path).c_str(), nullptr);
+    std::string all((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return all;
+}
+// position right after "key:" where key starts a line (top level); npos if absent
+inline size_t top_key(const std::string& t, const std::string& key, size_t from = 0) {
+    for (size_t p = t.find(key + ":", from); p != std::string::npos; p = t.find(key + ":", p + 1))
+        if (p == 0 || t[p - 1] == '\n') return p + key.size() + 1;
+    return std::string::npos;
+}
+inline bool scalar(const std::string& t, const std::string& key, double* v) {
+    size_t p = top_key(t, key);
+    if (p == std::string::npos) return false;
+    *v = std::strtod(t.c_str() + p, nullptr);
+    return true;
+}
+// numbers of the next [...] group(s) starting at p: reads until `count` numbers were found or the text ends
+inline std::vector<double> numbers(const std::string& t, size_t p, size_t count, size_t* endp = nullptr) {
+    std::vector<double> out;
+    while (p < t.size() && out.size() < count) {
+        const char c = t[p];
+        if ((c >= '0' && c <= '9') || c == '-' || c == '+' || (c == '.' && p + 1 < t.size() && t[p + 1] >= '0' && t[p + 1] <= '9')) {
+            char* e = nullptr;
+            out.push_back(std::strtod(t.c_str() + p, &e));
+            p = (size_t)(e - t.c_str());
+        } else {
+            p++;
+        }
+    }
+    if (endp) *endp = p;
+    return out;
+}
+// !!opencv-matrix block: rows, cols and rows*cols values of data: [...]
+inline bool matrix(const std::string& t, const std::string& key, int* rows, int* cols, std::vector<double>* data) {
+    size_t p = top_key(t, key);
+    if (p == std::string::npos) return false;
+    size_t r = t.find("rows:", p), c = t.find("cols:", p), d = t.find("data:", p);
+    if (r == std::string::npos || c == std::string::npos || d == std::string::npos) return false;
+    *rows = (int)std::strtol(t.c_str() + r + 5, nullptr, 10);
+    *cols = (int)std::strtol(t.c_str() + c + 5, nullptr, 10);
+    if (*rows <= 0 || *cols <= 0) return false;
+    *data = numbers(t, d + 5, (size_t)*rows * *cols);
+    return data->size() == (size_t)*rows * *cols;
+}
+}  // namespace yml_
+
 class CameraParameters {
 public:
     cv::Mat_<float> CameraMatrix;  // 3x3 (fx 0 cx, 0 fy cy, 0 0 1)
@@ -156,6 +210,23 @@ public:
         CamSize = size;
     }
     bool isValid() const { return !CameraMatrix.empty() && !Distorsion.empty() && CamSize.width != -1 && CamSize.height != -1; }
+    // cameraparameters.cpp:187-222: image_width / image_height, camera_matrix -> float, the first 5 distortion coefficients -> float
+    void readFromXMLFile(const std::string& filePath) {
+        const std::string t = yml_::slurp(filePath);
+        double w = -1, h = -1;
+        yml_::scalar(t, "image_width", &w), yml_::scalar(t, "image_height", &h);
+        int kr = 0, kc = 0, dr = 0, dc = 0;
+        std::vector<double> K, D;
+        if (!yml_::matrix(t, "camera_matrix", &kr, &kc, &K) || K.size() != 9)
+            arucohip_throw_(ARUCOHIP_E_INVALID, ("File :" + filePath + " does not contains valid camera matrix").c_str(), nullptr);
+        if (w == -1 || h == 0) arucohip_throw_(ARUCOHIP_E_INVALID, ("File :" + filePath + " does not contains valid camera dimensions").c_str(), nullptr);
+        if (!yml_::matrix(t, "distortion_coefficients", &dr, &dc, &D) || D.size() < 4)
+            arucohip_throw_(ARUCOHIP_E_INVALID, ("File :" + filePath + " does not contains valid distortion_coefficients").c_str(), nullptr);
+        float Kf[9], Df[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 9; i++) Kf[i] = (float)K[i];
+        for (size_t i = 0; i < 5 && i < D.size(); i++) Df[i] = (float)D[i];
+        setParams(Kf, Df, 5, cv::Size((int)w, (int)h));
+    }
     // cameraparameters.cpp:166-179
     void resize(cv::Size size) {
         if (!isValid()) arucohip_throw_(ARUCOHIP_E_INVALID, "invalid camera parameters", nullptr);
@@ -269,6 +340,31 @@ public:
     enum MarkerInfoType { NONE = -1, PIX = 0, METERS = 1 };
     int mInfoType;
     BoardConfiguration() : mInfoType(NONE) {}
+    // board.cpp:52-56 + src/serialization.cpp:94-120: aruco_bc_nmarkers, aruco_bc_mInfoType, aruco_bc_markers: - { id:.., corners:[ [x,y,z] x4 ] }
+    void readFromFile(const std::string& sfile) {
+        const std::string t = yml_::slurp(sfile);
+        double nm = -1, it = -1;
+        if (!yml_::scalar(t, "aruco_bc_nmarkers", &nm)) arucohip_throw_(ARUCOHIP_E_INVALID, "invalid file type", nullptr);
+        yml_::scalar(t, "aruco_bc_mInfoType", &it);
+        mInfoType = (int)it;
+        ids.clear(), objPoints.clear();
+        size_t p = yml_::top_key(t, "aruco_bc_markers");
+        while (p != std::string::npos) {
+            size_t q = t.find("id:", p);
+            if (q == std::string::npos) break;
+            ids.push_back((int)std::strtol(t.c_str() + q + 3, nullptr, 10));
+            size_t c = t.find("corners:", q);
+            if (c == std::string::npos) arucohip_throw_(ARUCOHIP_E_INVALID, "BoardConfiguration: marker without corners", nullptr);
+            size_t end = c;
+            std::vector<double> v = yml_::numbers(t, c + 8, 12, &end);
+            if (v.size() != 12) arucohip_throw_(ARUCOHIP_E_INVALID, "BoardConfiguration: a marker needs 4 corners", nullptr);
+            std::vector<cv::Point3f> pts(4);
+            for (int k = 0; k < 4; k++) pts[k] = cv::Point3f((float)v[3 * k], (float)v[3 * k + 1], (float)v[3 * k + 2]);
+            objPoints.push_back(pts);
+            p = end;
+        }
+        if ((int)ids.size() != (int)nm) arucohip_throw_(ARUCOHIP_E_INVALID, "BoardConfiguration: aruco_bc_nmarkers does not match the marker list", nullptr);
+    }
     bool isExpressedInMeters() const { return mInfoType == METERS; }
     bool isExpressedInPixels() const { return mInfoType == PIX; }
     const std::vector<cv::Point3f>& getMarkerInfo(int id) const {  // board.cpp:60-66
