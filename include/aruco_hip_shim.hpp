@@ -2,9 +2,11 @@
 //
 //   aruco::MarkerDetector   /root/reference/src/markerdetector.h:42-310
 //   aruco::Marker           /root/reference/src/marker.h:43-140
-//   aruco::CameraParameters /root/reference/src/cameraparameters.h:36-127 (data + resize only)
-//   aruco::BoardConfiguration, aruco::Board  /root/reference/src/board.h:54-137 (data only)
+//   aruco::CameraParameters /root/reference/src/cameraparameters.h:36-127 (data, resize, readFromXMLFile, GL / Ogre projection)
+//   aruco::BoardConfiguration, aruco::Board  /root/reference/src/board.h:54-137 (data, readFromFile, GL / Ogre pose)
 //   aruco::BoardDetector    /root/reference/src/boarddetector.h:40-148
+//   aruco::Dictionary, aruco::MarkerCode, aruco::HighlyReliableMarkers  /root/reference/src/highlyreliablemarkers.h:50-260
+//                           (dictionary files, loadDictionary, the decoder token for setMakerDetectorFunction)
 //
 // Same member names, argument meaning and failure behaviour (CV_Assert -> cv::Exception) as the reference, so a caller
 // of the reference compiles against this header and links libarucohip.so instead of libaruco + OpenCV imgproc/calib3d.
