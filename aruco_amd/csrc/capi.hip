@@ -227,6 +227,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
     b.cap_cdesc = (uint32_t)lim->contours_per_frame;   // per plane
     b.cap_pool = (uint32_t)lim->points_per_frame;       // per plane
+    // pool offsets are 32-bit (ContourDesc::pool_off = plane * cap_pool + offset)
+    if (P * (size_t)b.cap_pool > 0xFFFFFFF0ull) b.cap_pool = (uint32_t)(0xFFFFFFF0ull / P);
     b.cap_quads = std::min(lim->candidates_per_frame * 2, 512);
     b.cap_cands = lim->candidates_per_frame;
     b.cap_markers = lim->markers_per_frame;
@@ -491,6 +493,7 @@ static int ensure_patches(arucohip_handle* h, const DetectParams& dp) {
 // the long walks keep their checkpoint rings in HBM; (re)size the space for this batch
 static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
     size_t need = walk_scratch_words(nplanes, dp);
+    if (need > 0xFFFFFFF0ull) return fail(h, ARUCOHIP_E_CAPACITY, "batch too large for 32-bit checkpoint offsets: fewer frames per batch or a smaller max size");
     if (need <= h->scratch_words) return ARUCOHIP_OK;
     if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
     h->buf.walk_scratch = nullptr, h->scratch_words = 0;

@@ -209,7 +209,7 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "frames/sec at %dx%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec at %d\u00d7%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("3840x2160 6x4 board frames (24 markers), detect + batched BoardDetector solvePnP (config 4)" if board is not None else
