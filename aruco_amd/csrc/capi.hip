@@ -794,7 +794,7 @@ int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t
     if (h->d_hrm) HIPCHK(h, hipFree(h->d_hrm));
     h->d_hrm = nullptr, h->hrm_count = 0, h->hrm_n = 0;
     if (count > 0) {
-        if (!codes || n < 2 || n > 5 || count > 4096) return fail(h, ARUCOHIP_E_UNSUPPORTED, "dictionary: 2 <= n <= 5, count <= 4096");
+        if (!codes || n < 2 || n > 8 || count > 4096) return fail(h, ARUCOHIP_E_UNSUPPORTED, "dictionary: 2 <= n <= 8, count <= 4096");
         HIPCHK(h, hipMalloc((void**)&h->d_hrm, (size_t)count * sizeof(uint64_t)));
         HIPCHK(h, hipMemcpy(h->d_hrm, codes, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice));
         h->hrm_n = n, h->hrm_count = count, h->hrm_tau0 = tau0, h->hrm_rate = correction_rate;

@@ -459,11 +459,11 @@ __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
 }
 
 // 5d' — highly reliable markers: HighlyReliableMarkers::detect, src/highlyreliablemarkers.cpp:332-383.
-// One wavefront per candidate: lane = inner cell (n*n <= 25), majority vote on the Otsu-binarised patch, the code and its
+// One wavefront per candidate: lane = inner cell (n*n <= 64), majority vote on the Otsu-binarised patch, the code and its
 // three rotations (MarkerCode::set :113-142) through ballots, then the lanes share the dictionary: nearest entry over the
 // four rotations with the reference's first-minimum order (entries ascending, then rotations), accepted if its Hamming
 // distance is at most the correction distance; an exact match is the distance-0 case (the reference finds it through
-// 32-bit ids that are unique for n <= 5).
+// 32-bit ids that are unique for n <= 5 and overflow beyond; the nearest-entry search is the intended behaviour for every n).
 struct HrmArgs {
     int n, count;
     uint32_t correction;

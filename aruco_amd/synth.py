@@ -106,10 +106,10 @@ def _poly_mask(shape, quad, scale):
     return y0, y1, x0, x1, m
 
 
-def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=60, jitter=0.08, quiet=1):
+def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=60, jitter=0.08, quiet=1, cells=7, id_pool=1024):
     """Random non-overlapping marker placement. Returns list of dicts(id, quad (4x2 TL,TR,BR,BL of the 7x7 marker),
     quad_q (quiet-zone quad))."""
-    ids = rng.choice(1024, size=n_markers, replace=False)
+    ids = rng.choice(id_pool, size=n_markers, replace=False)   # cells = marker cells per side incl. the black border
     sc = 4
     occ = np.zeros(((height + sc - 1) // sc, (width + sc - 1) // sc), bool)
     out = []
@@ -128,9 +128,9 @@ def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=
             base = base + rng.uniform(-jitter, jitter, size=(4, 2)) * s  # mild perspective
             quad = base @ R.T + np.array([cx, cy])
             # quiet-zone quad: extend the marker's own projective frame by `quiet` cells
-            Hm = _homography([(0, 0), (7, 0), (7, 7), (0, 7)], [tuple(p) for p in quad])
+            Hm = _homography([(0, 0), (cells, 0), (cells, cells), (0, cells)], [tuple(p) for p in quad])
             qq = []
-            for (u, v) in [(-quiet, -quiet), (7 + quiet, -quiet), (7 + quiet, 7 + quiet), (-quiet, 7 + quiet)]:
+            for (u, v) in [(-quiet, -quiet), (cells + quiet, -quiet), (cells + quiet, cells + quiet), (-quiet, cells + quiet)]:
                 p = Hm @ np.array([u, v, 1.0])
                 qq.append(p[:2] / p[2])
             qq = np.array(qq)
@@ -156,7 +156,7 @@ def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=
     return out
 
 
-def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quiet=1, gen=None):
+def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quiet=1, gen=None, cells=7, table_fn=None):
     """Rasterise one frame (uint8 tensor HxW on `device`) for a layout from frame_layout()."""
     dev = torch.device(device)
     base = rng.uniform(150, 210)
@@ -167,8 +167,8 @@ def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quie
     for mk in layout:
         black = rng.uniform(15, 45)
         white = rng.uniform(215, 245)
-        t = _marker_table(mk["id"], quiet, black, white)
-        _paint_quad(img, mk["quad_q"], t, 7 + 2 * quiet, -quiet)
+        t = (table_fn or _marker_table)(mk["id"], quiet, black, white)
+        _paint_quad(img, mk["quad_q"], t, cells + 2 * quiet, -quiet)
     if noise_sigma > 0:
         if gen is None:
             gen = torch.Generator(device=dev)
@@ -189,6 +189,27 @@ def make_stream(n_frames, width=1920, height=1080, seed=4711, n_markers=20, devi
         frames[f] = render_frame(lay, width, height, rng, device=device, noise_sigma=noise_sigma)
         truth.append(lay)
     return frames, truth
+
+
+def make_hrm_frame(markers, width=1280, height=720, seed=7, n_markers=12, device="cpu", noise_sigma=1.5):
+    """One frame with highly reliable markers: `markers` = the dictionary's bit strings (n*n characters, '1' = white cell),
+    drawn like MarkerCode::getImg (src/highlyreliablemarkers.cpp:238-260: n x n code inside a one-cell black border).
+    Returns (uint8 frame [H,W], layout with id = position in the dictionary)."""
+    n = int(round(len(markers[0]) ** 0.5))
+    cells = n + 2
+    rng = np.random.RandomState(seed)
+    scale = max(width, height) / 1920.0
+    lay = frame_layout(rng, width, height, n_markers=min(n_markers, len(markers)), side_range=(110 * scale * 1.5, 220 * scale * 1.5),
+                       margin=int(60 * scale), cells=cells, id_pool=len(markers))
+
+    def table(marker_id, quiet, black, white):
+        t = np.full((cells + 2 * quiet, cells + 2 * quiet), float(white), np.float32)
+        t[quiet:quiet + cells, quiet:quiet + cells] = float(black)
+        bits = np.array([c == "1" for c in markers[marker_id]]).reshape(n, n)
+        t[quiet + 1:quiet + 1 + n, quiet + 1:quiet + 1 + n] = np.where(bits, float(white), float(black))
+        return t
+
+    return render_frame(lay, width, height, rng, device=device, noise_sigma=noise_sigma, cells=cells, table_fn=table), lay
 
 
 # ---------------------------------------------------------------------------------------------

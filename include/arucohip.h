@@ -131,11 +131,14 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
                           int out_on_device);
 /* SURVEY §8 row f1 — highly reliable markers: HighlyReliableMarkers::loadDictionary (src/highlyreliablemarkers.cpp:311-329).
  * codes[i] = marker i of the dictionary as n*n bits, bit y*n+x = cell (y, x) ('1' in aruco::Dictionary's bit strings),
- * n <= 5 (the reference's 32-bit marker ids are unique up to there), count <= 4096; tau0 = Dictionary::tau0,
+ * n <= 8, count <= 4096; tau0 = Dictionary::tau0,
  * correction_rate = correctionDistanceRate (the reference's default is 1). With params.decoder_kind = ARUCOHIP_DECODER_HRM
  * the candidates are then decoded like HighlyReliableMarkers::detect (:332-383) — id = position in the dictionary — which
  * is what MarkerDetector::setMakerDetectorFunction(HighlyReliableMarkers::detect) selects in the reference; the warp size
- * should be a multiple of n + 2 (the reference's apps use (n + 2) * 8). count = 0 drops the dictionary. */
+ * should be a multiple of n + 2 (the reference's apps use (n + 2) * 8). count = 0 drops the dictionary.
+ * For n >= 6 the reference's exact-match shortcut compares 32-bit ids built with `2 << bit` (:137-138), which overflow;
+ * the nearest-entry search it falls back to — the intended behaviour, identical whenever the ids are unique — is what runs
+ * here for every n. */
 int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t* codes, int tau0, float correction_rate);
 
 /* SURVEY §8 row f3 — frames with three interleaved 8-bit channels in B,G,R order (what cv::imread / cv::VideoCapture

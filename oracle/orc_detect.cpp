@@ -93,7 +93,7 @@ int fiducial_detect(uint8_t* patch, int size, int* nrot) {
 // BalancedBinaryTree::findId :505-518) or, failing that, the nearest entry within the correction distance
 // (Dictionary::distance :262-274 with MarkerCode::distance :160-170: first minimum over entries, then over rotations).
 // Returns the entry's position in the dictionary. The reference looks exact matches up through 32-bit ids (2 << bit
-// position, :137-138), which are unique for n <= 5; with unique ids an exact match is the distance-0 case of the
+// position, :137-138), which are unique for n <= 5 (and overflow for larger n); with unique ids an exact match is the distance-0 case of the
 // nearest-entry search with the same first-minimum order, which is what is restated here.
 int hrm_detect(uint8_t* patch, int size, const HrmDict& d, int* nrot) {
     *nrot = 0;

@@ -452,3 +452,29 @@ def test_hrm_decoder(env):
         _compare_markers(h.detect(gray), o.detect(gray))
     finally:
         h.close()
+
+
+def test_hrm_larger_dictionaries(env):
+    """6x6 and 8x8 dictionaries (64-bit codes, all 64 lanes vote): device == CPU restatement on synthetic frames."""
+    from tests.util import make_hrm_dictionary
+    capi, orc, synth = env["capi"], env["orc"], env["synth"]
+    for n, tau in ((6, 9), (8, 14)):
+        D = make_hrm_dictionary(n, 30, tau)
+        fr, lay = synth.make_hrm_frame(D, width=1280, height=720, seed=7 + n, n_markers=10, device="cuda")
+        g = fr.cpu().numpy()
+        h = capi.Handle(1280, 720, max_batch=1)
+        try:
+            p = h.get_params()
+            p.warp_size = (n + 2) * 8
+            h.set_params(p)
+            h.set_dictionary(D, tau)
+            o = orc.Oracle(warp_size=(n + 2) * 8)
+            o.set_hrm_dictionary(D, tau)
+            got, ref = h.detect(g), o.detect(g)
+            _compare_markers(got, ref)
+            assert [int(m["id"]) for m in got] == sorted(m["id"] for m in lay)
+            _, did, drot = h.debug_candidates(0)
+            cands = o.candidates()
+            assert [int(v) for v in did] == [c["id"] for c in cands]
+        finally:
+            h.close()

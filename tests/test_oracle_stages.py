@@ -116,3 +116,17 @@ def test_bgr2gray_matches_the_fixture_pipeline():
     assert np.array_equal(orc.bgr2gray(bgr), exp)
     g = rng.randint(0, 256, size=(8, 9)).astype(np.uint8)
     assert np.array_equal(orc.bgr2gray(np.repeat(g[..., None], 3, axis=2)), g)   # equal channels reproduce the value
+
+
+def test_hrm_synthetic_6x6_and_8x8():
+    """Larger dictionaries of row f1 (the reference ships d6x6 ... d8x8): the restatement finds exactly the rendered markers
+    of a synthetic frame (MarkerCode::getImg layout), in any orientation."""
+    from aruco_amd import synth
+    from tests.util import make_hrm_dictionary
+    for n, tau in ((6, 9), (8, 14)):
+        D = make_hrm_dictionary(n, 30, tau)
+        fr, lay = synth.make_hrm_frame(D, width=1280, height=720, seed=7 + n, n_markers=10)
+        o = orc.Oracle(warp_size=(n + 2) * 8)
+        o.set_hrm_dictionary(D, tau)
+        ms = o.detect(fr.numpy())
+        assert [m["id"] for m in ms] == sorted(m["id"] for m in lay)
