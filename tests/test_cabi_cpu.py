@@ -52,3 +52,27 @@ def test_shim_header_compiles_without_opencv(tmp_path):
     subprocess.run(cmd, check=True)
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "Usage" in r.stderr
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libarucohip.so the product raises instead of computing anything (the oracle is test
+    infrastructure and is never imported by aruco_amd)."""
+    import importlib
+    import pytest
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "library_path", lambda: str(tmp_path / "libarucohip.so"))
+    with pytest.raises(capi.ArucoHipError):
+        capi.load()
+    with pytest.raises(capi.ArucoHipError):
+        capi.Handle(640, 480)
+    # nothing under aruco_amd/ imports the oracle
+    pkg = os.path.join(ROOT, "aruco_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, name)).read(), name
+    csrc = os.path.join(pkg, "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, name)).read()
+            assert "orc.h" not in txt and "liborc" not in txt, name
+    importlib.reload(capi)   # leave the module in its normal state for the other tests
