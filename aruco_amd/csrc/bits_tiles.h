@@ -26,11 +26,6 @@ __device__ __forceinline__ uint32_t tb_assemble(uint32_t up, uint32_t mid, uint3
     return (mid >> 2) | ((up >> 2) << 1) | ((up & 2u) << 1) | ((up & 1u) << 3) | ((mid & 1u) << 4) | (dn << 5);
 }
 
-// 8 pixels of row y starting at tile column tx (bits x&7)
-__device__ __forceinline__ uint32_t tb_row_byte(const uint64_t* __restrict__ tiles, int tnx, int tx, int y) {
-    return (uint32_t)(tiles[(size_t)(y >> 3) * tnx + tx] >> (8 * (y & 7))) & 0xFFu;
-}
-
 // 3x3 neighbourhood straight from the tiles (no cache): used where only a few steps are walked
 __device__ __forceinline__ uint32_t tb_mask_direct(const uint64_t* __restrict__ tiles, int tnx, uint32_t pos) {
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);

@@ -20,12 +20,6 @@
 
 namespace ah {
 
-// direction d (0=E,1=NE,2=N,3=NW,4=W,5=SW,6=S,7=SE; y grows downwards) -> pixel step, from packed 2-bit tables
-__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
-__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
-
-__device__ __forceinline__ bool raster_lt(int y, int x, int ty, int tx) { return y < ty || (y == ty && x < tx); }
-
 // Initial clockwise search of icvFetchContour: returns direction to the predecessor pixel, or -1 for an isolated pixel.
 __device__ __forceinline__ int first_dir(uint32_t m, int s_end) {
     int s = s_end;
@@ -34,19 +28,6 @@ __device__ __forceinline__ int first_dir(uint32_t m, int s_end) {
         if ((m >> s) & 1) break;
     } while (s != s_end);
     return s == s_end ? -1 : s;
-}
-
-// One counter-clockwise step: from direction `s` (pointing at the previous pixel) find the next border pixel.
-// Returns the new direction d; *examined = bit mask of the zero neighbours passed over.
-__device__ __forceinline__ int next_dir(uint32_t m, int s, uint32_t* examined) {
-    uint32_t mm = m | (m << 8);
-    int sh = (s + 1) & 7;
-    uint32_t rot = (mm >> sh) & 0xFFu;
-    int k = __builtin_ctz(rot | 0x100u);
-    uint32_t ex = (1u << k) - 1u;           // k zero neighbours examined, starting at direction s+1
-    ex = ((ex << sh) | (ex << sh >> 8)) & 0xFFu;
-    *examined = ex;
-    return (sh + k) & 7;
 }
 
 // Run rule on the tiled image: can the crack's pixel be the raster-first pixel of its component (outer: pixel (x,y) set)
@@ -713,7 +694,6 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
                                                int& s_outn) {
     const int lane = threadIdx.x;
     const int count = cd.n;
-    const int W = a.width;
     // ---- points: already emitted (segment pipeline) or every lane resumes the walk at one checkpoint and records CK points
     if (a.from_pool) {
         if (LDSP)

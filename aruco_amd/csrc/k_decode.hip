@@ -15,8 +15,6 @@
 
 namespace ah {
 
-constexpr int MAX_WARP = 128;
-
 // 8x8 dense solve, partial pivoting, on LDS arrays (lane 0).
 __device__ static bool solve8(double* A, double* b) {
     const int n = 8;
@@ -103,19 +101,6 @@ __device__ __forceinline__ uint8_t warp_pixel(const uint8_t* src, int W, int H, 
     long long X = __double2ll_rn(fX), Y = __double2ll_rn(fY);
     if (X >= 0 && X < W && Y >= 0 && Y < H) return src[(size_t)Y * stride + X];
     return 0;
-}
-
-__device__ static int hamm_dist(const uint8_t b[5][5]) {
-    const uint8_t words[4] = {0x10, 0x17, 0x09, 0x0E};
-    int dist = 0;
-    for (int y = 0; y < 5; y++) {
-        int row = 0;
-        for (int x = 0; x < 5; x++) row |= b[y][x] << (4 - x);
-        int best = 100000;
-        for (int p = 0; p < 4; p++) best = min(best, __popc((unsigned)(row ^ words[p])));
-        dist += best;
-    }
-    return dist;
 }
 
 // The decode stage is four small kernels so that the serial double-precision parts (8x8 homography solve, 256-bin Otsu

@@ -45,8 +45,7 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xFFu; }
 
 // value of the neighbouring lane through the DPP wave shift (a VALU operand modifier on gfx9, no LDS crossbar trip):
-// from_left = lane i receives lane i-1 (wave_shr:1), from_right = lane i receives lane i+1 (wave_shl:1); lane 0 / 63 get 0
-__device__ __forceinline__ uint32_t from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+// from_right = lane i receives lane i+1 (wave_shl:1), lane 63 gets 0; the halo-aware variants live in the kernel
 __device__ __forceinline__ uint32_t from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
 
 constexpr int STRIP = 256;       // pixels per wave and row: one aligned 256-byte load and store per row
