@@ -28,5 +28,28 @@ int main(int argc, char** argv) {
     } catch (const std::exception&) {
         std::printf("throws\n");
     }
+    // further malformed inputs (argv[3..]): every one must throw, none may crash
+    for (int i = 3; i < argc; i++) {
+        int thrown = 0;
+        try {
+            aruco::CameraParameters c2;
+            c2.readFromXMLFile(argv[i]);
+        } catch (const std::exception&) {
+            thrown |= 1;
+        }
+        try {
+            aruco::BoardConfiguration b2;
+            b2.readFromFile(argv[i]);
+        } catch (const std::exception&) {
+            thrown |= 2;
+        }
+        try {
+            aruco::Dictionary d2;
+            d2.fromFile(argv[i]);
+        } catch (const std::exception&) {
+            thrown |= 4;
+        }
+        std::printf("bad%d %d\n", i - 3, thrown);
+    }
     return 0;
 }

@@ -36,7 +36,15 @@ def test_shim_yaml_readers(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_yaml.cpp"), "-o", str(exe),
                     "-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"),
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    out = subprocess.run([str(exe), str(tmp_path / "intrinsics.yml"), str(tmp_path / "board.yml")], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    bad = []
+    for k, text in enumerate(["", "%YAML:1.0\nimage_width: 640\nimage_height: 480\ncamera_matrix: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ 1., 2. ]\n",
+                              "%YAML:1.0\naruco_bc_nmarkers: 2\naruco_bc_mInfoType: 0\naruco_bc_markers:\n   - { id:1, corners:[ [ 0., 0., 0. ], [ 1., 0., 0. ] ] }\n",
+                              "%YAML:1.0\nnmarkers: 2\nmarkersize: 4\ntau0: 4\nmarker_0: \"1011\"\nmarker_1: \"1001010011000100\"\n"]):
+        path = tmp_path / ("bad%d.yml" % k)
+        path.write_text(text)
+        bad.append(str(path))
+    bad.append(str(tmp_path / "does_not_exist.yml"))
+    out = subprocess.run([str(exe), str(tmp_path / "intrinsics.yml"), str(tmp_path / "board.yml")] + bad, stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
     assert [int(v) for v in out[0].split()] == [intr["width"], intr["height"]]
     assert np.array_equal(np.array(out[1].split(), np.float32), np.array(intr["K"], np.float32))
     assert np.array_equal(np.array(out[2].split(), np.float32), np.array(intr["dist"], np.float32))
@@ -46,3 +54,7 @@ def test_shim_yaml_readers(tmp_path):
         assert int(v[0]) == i
         assert np.array_equal(np.array(v[1:], np.float32), np.array(o, np.float32).reshape(-1))
     assert out[4 + len(bc["ids"])] == "throws"
+    # empty file, truncated matrix, marker with two corners, dictionary entry with too few bits, missing file:
+    # all three readers reject all five (bit 1 = CameraParameters, 2 = BoardConfiguration, 4 = Dictionary)
+    tail = out[5 + len(bc["ids"]):]
+    assert tail == ["bad%d 7" % k for k in range(5)], tail
