@@ -124,6 +124,10 @@ def main():
                         "warp_size": (int(d["markersize"]) + 2) * 8, "marker_size": 1.0}}
     with open(os.path.join(OUT, "hrm.json"), "w") as f:
         json.dump(doc, f, indent=1)
+    # test/core_tests.cpp:355-382 (Aruco.RefineFail): a frame on which the LINES refinement once failed; the test only
+    # requires that detection goes through (same dictionary and settings, warp size 48)
+    rgb = np.asarray(Image.open(os.path.join(REF, "hrm/refine-fail.png")).convert("RGB"))
+    write_pgm(os.path.join(OUT, "hrm_refine_fail.pgm"), bgr2gray_cv3(rgb))
     gl = load_cv_yaml(os.path.join(REF, "board/expected_gl.yml"))
     with open(os.path.join(OUT, "board_gl.json"), "w") as f:
         json.dump({"gldata": [[float(v) for v in row] for row in gl["gldata"]]}, f, indent=1)

@@ -478,3 +478,27 @@ def test_hrm_larger_dictionaries(env):
             assert [int(v) for v in did] == [c["id"] for c in cands]
         finally:
             h.close()
+
+
+def test_refine_fail_frame(env):
+    """Reference test Aruco.RefineFail (test/core_tests.cpp:355-382) through the HIP path: goes through and equals the
+    CPU restatement (degenerate LINES fits included)."""
+    import os
+    from tests.util import read_pgm, GOLDEN
+    capi, orc = env["capi"], env["orc"]
+    gray = read_pgm(os.path.join(GOLDEN, "hrm_refine_fail.pgm"))
+    _, doc = load_case("hrm")
+    intr, dic = doc["intrinsics"], doc["dictionary"]
+    h = capi.Handle(640, 480, max_batch=1)
+    try:
+        p = h.get_params()
+        p.thres_param1, p.thres_param2, p.min_size, p.max_size, p.warp_size = 21, 7, 0.005, 0.5, 48
+        h.set_params(p)
+        h.set_dictionary(dic["markers"], dic["tau0"])
+        o = orc.Oracle(thres_p1=21, thres_p2=7, min_size=0.005, max_size=0.5, warp_size=48)
+        o.set_hrm_dictionary(dic["markers"], dic["tau0"])
+        got = h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        ref = o.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        _compare_markers(got, ref, pose=True)
+    finally:
+        h.close()

@@ -84,3 +84,19 @@ def test_hrm_golden():
         assert np.max(np.abs(m["corners"] - np.array(e["corners"]))) < CORNER_ABS_TOL
         assert rel_err(m["rvec"], e["Rvec"]) < POSE_REL_TOL
         assert rel_err(m["tvec"], e["Tvec"]) < POSE_REL_TOL
+
+
+def test_refine_fail_frame():
+    """Reference test Aruco.RefineFail (test/core_tests.cpp:355-382): a frame on which the LINES refinement once broke;
+    the test only demands that detect() goes through. Same here, plus finite results."""
+    from tests.util import read_pgm, GOLDEN
+    import os
+    gray = read_pgm(os.path.join(GOLDEN, "hrm_refine_fail.pgm"))
+    _, doc = load_case("hrm")
+    intr, dic = doc["intrinsics"], doc["dictionary"]
+    o = orc.Oracle(thres_p1=21, thres_p2=7, min_size=0.005, max_size=0.5, warp_size=48)
+    o.set_hrm_dictionary(dic["markers"], dic["tau0"])
+    ms = o.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    assert len(ms) >= 10
+    for m in ms:
+        assert np.isfinite(m["corners"]).all() and np.isfinite(m["rvec"]).all() and np.isfinite(m["tvec"]).all()
