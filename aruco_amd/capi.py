@@ -47,7 +47,8 @@ class BoardOut(C.Structure):
 class Limits(C.Structure):
     _fields_ = [("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
                 ("max_thres_planes", C.c_int32), ("triggers_per_frame", C.c_int32), ("contours_per_frame", C.c_int32),
-                ("points_per_frame", C.c_int32), ("candidates_per_frame", C.c_int32), ("markers_per_frame", C.c_int32)]
+                ("points_per_frame", C.c_int32), ("candidates_per_frame", C.c_int32), ("markers_per_frame", C.c_int32),
+                ("long_walks_per_plane", C.c_int32)]
 
 
 MARKER_DTYPE = np.dtype([("id", "<i4"), ("corners", "<f4", (8,)), ("ssize", "<f4"), ("has_pose", "<i4"),
@@ -66,6 +67,9 @@ SYMBOLS = [
     "arucohip_debug_counters", "arucohip_board_detect_batch",
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
     "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray", "arucohip_set_dictionary",
+    "arucohip_set_decoder_callback",
+    "arucohip_mgpu_device_count", "arucohip_mgpu_create", "arucohip_mgpu_destroy", "arucohip_mgpu_size", "arucohip_mgpu_handle",
+    "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
 ]
 
 _lib = None
@@ -130,6 +134,18 @@ def load():
     L.arucohip_ogre_pose.argtypes = [vp, vp, vp, vp]
     L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
     L.arucohip_ogre_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
+    L.arucohip_set_decoder_callback.argtypes = [vp, vp, vp]
+    L.arucohip_mgpu_create.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    L.arucohip_mgpu_destroy.argtypes = [vp]
+    L.arucohip_mgpu_destroy.restype = None
+    L.arucohip_mgpu_size.argtypes = [vp]
+    L.arucohip_mgpu_handle.argtypes = [vp, i]
+    L.arucohip_mgpu_handle.restype = vp
+    L.arucohip_mgpu_set_params.argtypes = [vp, vp]
+    L.arucohip_mgpu_last_error_string.argtypes = [vp]
+    L.arucohip_mgpu_last_error_string.restype = C.c_char_p
+    L.arucohip_mgpu_detect_batch.argtypes = [vp, vp, i, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp]
+    L.arucohip_mgpu_detect_streams.argtypes = [vp, vp, vp, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -401,6 +417,52 @@ class Handle:
                                                      int(bool(y_perp)), out, _ptr(prob)))
         return [{"n_markers": out[f].n_markers, "has_pose": out[f].has_pose, "rvec": np.array(out[f].rvec), "tvec": np.array(out[f].tvec),
                  "prob": float(prob[f])} for f in range(nframes)]
+
+
+class MultiGpu:
+    """arucohip_mgpu_*: frames sharded round-robin over device slots, marker blocks gathered (host or peer/xGMI)."""
+
+    GATHER_HOST, GATHER_PEER = 0, 1
+
+    def __init__(self, devices, max_width, max_height, frames_per_device, cap=64, flags=0, params=None):
+        self.L = load()
+        self.m = C.c_void_p()
+        p = params if params is not None else default_params()
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self.L.arucohip_mgpu_create(C.byref(p), _ptr(dv), len(dv), max_width, max_height, frames_per_device, cap, flags, C.byref(self.m))
+        if rc != OK:
+            raise ArucoHipError(rc, "arucohip_mgpu_create")
+        self.cap, self.per, self.G = cap, frames_per_device, len(dv)
+
+    def close(self):
+        if self.m:
+            self.L.arucohip_mgpu_destroy(self.m)
+            self.m = C.c_void_p()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise ArucoHipError(rc, (self.L.arucohip_mgpu_last_error_string(self.m) or b"").decode())
+
+    def detect_batch_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf, h, w = fr.shape
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((nf, self.cap), MARKER_DTYPE)
+        n = np.zeros(nf, np.int32)
+        self._chk(self.L.arucohip_mgpu_detect_batch(self.m, _ptr(fr), nf, w, h, w, w * h, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                                    float(marker_size), int(bool(y_perp)), _ptr(out), self.cap, _ptr(n)))
+        return [out[f, :n[f]].copy() for f in range(nf)]
+
+    def detect_streams(self, ptrs, counts, width, height, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        """ptrs[g] = device pointer of slot g's frames (resident on its device), counts[g] frames each."""
+        pa = (C.c_void_p * self.G)(*[C.c_void_p(int(x)) for x in ptrs])
+        ca = np.ascontiguousarray(counts, dtype=np.int32)
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((self.G * self.per, self.cap), MARKER_DTYPE)
+        n = np.zeros(self.G * self.per, np.int32)
+        self._chk(self.L.arucohip_mgpu_detect_streams(self.m, pa, _ptr(ca), width, height, width, width * height, _ptr(Ka), _ptr(da),
+                                                      0 if da is None else da.size, float(marker_size), int(bool(y_perp)), _ptr(out), self.cap, _ptr(n)))
+        return [[out[g * self.per + j, :n[g * self.per + j]].copy() for j in range(int(ca[g]))] for g in range(self.G)]
 
 
 # ---- OpenGL / Ogre conversions (host arithmetic; SURVEY §8 row f4)

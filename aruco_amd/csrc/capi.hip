@@ -46,6 +46,10 @@ struct arucohip_handle {
     uint64_t* d_hrm = nullptr;
     int hrm_n = 0, hrm_count = 0, hrm_tau0 = 0;
     float hrm_rate = 1.f;
+    // caller's own decoder (arucohip_set_decoder_callback)
+    arucohip_decoder_fn decoder_fn = nullptr;
+    void* decoder_user = nullptr;
+    int2* d_user_dec = nullptr;       // [cap_flat] {id, nRotations} returned by the callback
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
     size_t bits_bytes = 0;
     size_t patch_bytes = 0;           // capacity of buf.patches
@@ -135,6 +139,9 @@ void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height
     l->points_per_frame = (int)std::min<long>(std::max<long>(px / 8, 65536), 1 << 21);
     l->candidates_per_frame = 256;
     l->markers_per_frame = 128;
+    // a synthetic 1080p frame has ~200 long walks per plane, a cluttered one several times that; small batches can afford
+    // more rings (a ring is max contour length / 16 words)
+    l->long_walks_per_plane = l->max_batch <= 16 ? 8192 : l->max_batch <= 128 ? 2048 : 1024;
 }
 
 static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
@@ -147,7 +154,7 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
     if (p->thres_method != ARUCOHIP_THRES_FIXED && p->thres_method != ARUCOHIP_THRES_ADPT) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
     if (p->corner_method < ARUCOHIP_CORNER_NONE || p->corner_method > ARUCOHIP_CORNER_LINES) return fail(h, ARUCOHIP_E_INVALID, "bad corner method");
     if (p->use_locked_corners) return fail(h, ARUCOHIP_E_UNSUPPORTED, "locked corners are not on the accelerated path");
-    if (p->decoder_kind != ARUCOHIP_DECODER_FIDUCIAL_5X5 && p->decoder_kind != ARUCOHIP_DECODER_HRM) return fail(h, ARUCOHIP_E_INVALID, "bad decoder kind");
+    if (p->decoder_kind < ARUCOHIP_DECODER_FIDUCIAL_5X5 || p->decoder_kind > ARUCOHIP_DECODER_USER) return fail(h, ARUCOHIP_E_INVALID, "bad decoder kind");
     if (p->thres_param1_range < 0 || 2 * p->thres_param1_range + 1 > 16) return fail(h, ARUCOHIP_E_UNSUPPORTED, "threshold range too large");
     if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 > 15) return fail(h, ARUCOHIP_E_UNSUPPORTED, "SUBPIX window > 15");
     if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 < 1) return fail(h, ARUCOHIP_E_INVALID, "SUBPIX window < 1");
@@ -168,7 +175,7 @@ static void free_all(arucohip_handle* h) {
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_hrm), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -184,7 +191,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if (!out || !lim) return ARUCOHIP_E_INVALID;
     *out = nullptr;
     if (lim->max_width < 32 || lim->max_height < 32 || lim->max_width > 16383 || lim->max_height > 16383 || lim->max_batch < 1 ||
-        lim->max_thres_planes < 1 || lim->max_thres_planes > 16 || lim->candidates_per_frame > 512 || lim->markers_per_frame > 256)
+        lim->max_thres_planes < 1 || lim->max_thres_planes > 16 || lim->candidates_per_frame > 512 || lim->markers_per_frame > 256 ||
+        (long)lim->max_width * lim->max_height > (1L << 26) /* Quad::key holds a 26-bit raster index */)
         return ARUCOHIP_E_INVALID;
     arucohip_handle* h = new arucohip_handle();
     h->device = device;
@@ -225,6 +233,8 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     Buffers& b = h->buf;
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
+    b.long_cap = (uint32_t)std::min(std::max(lim->long_walks_per_plane, 64), 1 << 16);
+    h->lim.long_walks_per_plane = (int32_t)b.long_cap;
     b.cap_cdesc = (uint32_t)lim->contours_per_frame;   // per plane
     b.cap_pool = (uint32_t)lim->points_per_frame;       // per plane
     // pool offsets are 32-bit (ContourDesc::pool_off = plane * cap_pool + offset)
@@ -256,7 +266,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
     ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
     ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
-    ALLOC(b.gen_buf, P * (size_t)b.cap_trig * sizeof(uint2));
+    ALLOC(b.gen_buf, P * (size_t)b.long_cap * 4 * 20);   // [2 kinds][2 parities][P * long_cap] walk states (16 B) + ring ids (4 B)
     ALLOC(b.ring_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.gen_cnt, GEN_CNT_WORDS * sizeof(uint32_t));
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
@@ -442,6 +452,8 @@ static int make_detect_params(arucohip_handle* h, int W, int H, DetectParams* dp
         dp->hrm_n = h->hrm_n, dp->hrm_count = h->hrm_count, dp->hrm_codes = h->d_hrm;
         dp->hrm_correction = (uint32_t)(h->hrm_rate * (float)((h->hrm_tau0 - 1) / 2));   // highlyreliablemarkers.cpp:318
     }
+    if (p.decoder_kind == ARUCOHIP_DECODER_USER && !h->decoder_fn)
+        return fail(h, ARUCOHIP_E_INVALID, "decoder USER without a callback (arucohip_set_decoder_callback)");
     return ARUCOHIP_OK;
 }
 
@@ -492,13 +504,48 @@ static int ensure_patches(arucohip_handle* h, const DetectParams& dp) {
 
 // the long walks keep their checkpoint rings in HBM; (re)size the space for this batch
 static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectParams& dp) {
-    size_t need = walk_scratch_words(nplanes, dp);
+    size_t need = walk_scratch_words(nplanes, dp, h->buf.long_cap);
     if (need > 0xFFFFFFF0ull) return fail(h, ARUCOHIP_E_CAPACITY, "batch too large for 32-bit checkpoint offsets: fewer frames per batch or a smaller max size");
     if (need <= h->scratch_words) return ARUCOHIP_OK;
     if (h->buf.walk_scratch) HIPCHK(h, hipFree(h->buf.walk_scratch));
     h->buf.walk_scratch = nullptr, h->scratch_words = 0;
     HIPCHK(h, hipMalloc((void**)&h->buf.walk_scratch, need * sizeof(uint32_t)));
     h->scratch_words = need;
+    return ARUCOHIP_OK;
+}
+
+// Plugin boundary (markerdetector.h:65-78, :243-245): the caller's decoder runs on the host between the device's warp and
+// the rest of the pipeline. Candidates are decoded frame by frame in detectRectangles order like the loop at
+// markerdetector.cpp:350-368.
+static int user_decode_stage(arucohip_handle* h, const DetectParams& dp) {
+    hipStream_t s = h->stream;
+    const Buffers& b = h->buf;
+    uint32_t ncand = 0;
+    HIPCHK(h, hipMemcpyAsync(&ncand, b.counters + CNT_NCAND, sizeof(ncand), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    const uint32_t n = std::min(ncand, b.cap_flat);
+    if (!n) return ARUCOHIP_OK;
+    const size_t npx = (size_t)dp.warp_size * dp.warp_size;
+    std::vector<uint32_t> list(n);
+    std::vector<uint8_t> patches((size_t)n * npx), scratch(npx);
+    HIPCHK(h, hipMemcpyAsync(list.data(), b.cand_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(patches.data(), b.patches, patches.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return list[x] < list[y]; });   // frame << 16 | index
+    std::vector<int2> dec(n);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t i = order[k];
+        std::memcpy(scratch.data(), patches.data() + (size_t)i * npx, npx);
+        int nrot = 0;   // the reference leaves it uninitialised (markerdetector.cpp:354); 0 is the intent
+        const int id = h->decoder_fn(h->decoder_user, scratch.data(), dp.warp_size, &nrot);
+        dec[i] = make_int2(id < 0 ? -1 : id, nrot & 3);
+    }
+    if (!h->d_user_dec) HIPCHK(h, hipMalloc((void**)&h->d_user_dec, (size_t)b.cap_flat * sizeof(int2)));
+    HIPCHK(h, hipMemcpyAsync(h->d_user_dec, dec.data(), n * sizeof(int2), hipMemcpyHostToDevice, s));
+    launch_set_decoded(s, b, n, h->d_user_dec);
+    HIPCHK(h, hipStreamSynchronize(s));   // `dec` leaves scope
     return ARUCOHIP_OK;
 }
 
@@ -577,6 +624,10 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     launch_frame_candidates(s, g, nframes, dp, b);
     MARK(5);
     launch_decode(s, gray_dev, g, nframes, dp, b);
+    if (dp.decoder == ARUCOHIP_DECODER_USER) {
+        const int rc_ = user_decode_stage(h, dp);
+        if (rc_) return rc_;
+    }
     MARK(6);
     launch_refine_lines(s, g, nframes, dp, cam, b);
     MARK(7);
@@ -642,7 +693,8 @@ static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, 
 
 static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride, int channels = 1) {
     if (nframes < 1 || nframes > h->lim.max_batch) return fail(h, ARUCOHIP_E_INVALID, "nframes outside 1..max_batch");
-    if (W < 32 || H < 32 || (size_t)W * H > (size_t)h->lim.max_width * h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame larger than the handle was created for");
+    // every device array and packed field is sized per dimension (tile rows, 14-bit checkpoint coordinates, raster keys)
+    if (W < 32 || H < 32 || W > h->lim.max_width || H > h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame wider or taller than the handle was created for");
     if (row_stride < (size_t)W * channels) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width * channels");
     return ARUCOHIP_OK;
 }
@@ -736,6 +788,11 @@ static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nfra
                            out ? out + (size_t)off * cap : nullptr, cap, n_out + off, out_on_device);
         if (rc) {
             if (w != h) h->err = w->err;
+            // the workers that already have queued work still have to rejoin the caller's stream
+            const std::string keep = h->err;
+            (void)join_workers(h, chunks);
+            for (int k = 0; k < chunks; k++) (k == 0 ? h : h->kids[k - 1])->wait_thr = nullptr;
+            h->err = keep;
             return rc;
         }
     }
@@ -802,6 +859,17 @@ int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t
     for (auto* k : h->kids) {
         int rc = arucohip_set_dictionary(k, n, count, codes, tau0, correction_rate);
         if (rc) return rc;
+    }
+    return ARUCOHIP_OK;
+}
+
+int arucohip_set_decoder_callback(arucohip_handle* h, arucohip_decoder_fn fn, void* user) {
+    if (!h) return ARUCOHIP_E_INVALID;
+    h->decoder_fn = fn, h->decoder_user = user;
+    for (auto* k : h->kids) k->decoder_fn = fn, k->decoder_user = user;
+    if (!fn && h->params.decoder_kind == ARUCOHIP_DECODER_USER) {
+        h->params.decoder_kind = ARUCOHIP_DECODER_FIDUCIAL_5X5;
+        for (auto* k : h->kids) k->params.decoder_kind = ARUCOHIP_DECODER_FIDUCIAL_5X5;
     }
     return ARUCOHIP_OK;
 }
@@ -1102,6 +1170,12 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
     }
     if ((rc = join_workers(h, chunks))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // a frame with more member markers than the kernel's correspondence array holds is reported, not truncated silently
+    for (int c = 0; c < chunks; c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        HIPCHK(h, hipMemcpy(w->h_counters, w->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (w->h_counters[CNT_STATUS] & ST_MARKER_OVERFLOW) return fail(h, ARUCOHIP_E_CAPACITY, "a frame has more than 128 board markers");
+    }
     return ARUCOHIP_OK;
 }
 
@@ -1165,7 +1239,8 @@ int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, 
             for (int c = 0; c < 3; c++) o3.push_back((float)(q[c] * mpp));
         }
     int npts = nb * 4;
-    if (npts * 5 > 8192) return fail(h, ARUCOHIP_E_CAPACITY, "board with too many points");
+    // d_small_f holds obj[3 npts] + img[2 npts] + the reprojected points [2 npts]
+    if (npts * 7 > 8192) return fail(h, ARUCOHIP_E_CAPACITY, "board with too many points");
     HIPCHK(h, hipSetDevice(h->device));
     float zeros[4] = {0, 0, 0, 0};
     if (!dist || ndist == 0) dist = zeros, ndist = 4;
@@ -1199,6 +1274,12 @@ int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, 
             }
         }
         o3.swap(o3f), i2.swap(i2f);
+        // fewer than 4 surviving points: the reference's second cv::solvePnP would throw; like the batched kernel the
+        // board then has no pose
+        if (i2.size() / 2 < 4) {
+            *prob = float(nb) / float(nboard);
+            return ARUCOHIP_OK;
+        }
         if ((rc = solve((int)(i2.size() / 2)))) return rc;
     }
     if (y_perp) launch_rotate_x(h->stream, h->d_small_d);

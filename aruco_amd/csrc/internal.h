@@ -96,7 +96,8 @@ struct DetectParams {
     int min_contour, max_contour;   // contour length bounds (exclusive)
     int bx0, by0, bx1, by1;         // valid region of the border filter [bx0,bx1) x [by0,by1)
     int subpix_win;
-    // decoder: 0 = 5x5 fiducial, 1 = highly reliable markers with the handle's dictionary
+    // decoder: 0 = 5x5 fiducial, 1 = highly reliable markers with the handle's dictionary, 2 = host callback (the device
+    // only warps; ids come back through launch_set_decoded)
     int decoder;
     int hrm_n, hrm_count;
     uint32_t hrm_correction;        // largest Hamming distance that is still corrected
@@ -134,6 +135,7 @@ struct Buffers {
     int32_t* nmarkers;     // [F]
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;   // per plane
+    uint32_t long_cap;            // checkpoint rings (long walks) per plane and kind
     int seg_mode, grid_mask;      // contour pipeline: 0 = walkers, 1 = waypoint segments (grid spacing = grid_mask + 1)
     uint32_t cap_cdesc, cap_pool;   // per plane: cdesc [P][cap_cdesc], pool [P][cap_pool]
     int cap_quads, cap_cands, cap_markers;   // per frame
@@ -149,12 +151,13 @@ struct WalkFork {
     hipEvent_t forked, joined;
 };
 bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
-size_t walk_scratch_words(int nplanes, const DetectParams& p);   // capacity launch_walkers needs in Buffers::walk_scratch
+size_t walk_scratch_words(int nplanes, const DetectParams& p, uint32_t long_cap);   // capacity launch_walkers needs in Buffers::walk_scratch
 constexpr size_t GEN_CNT_WORDS = 2 * 32 * 32;                     // words of Buffers::gen_cnt
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, int pass = 0);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_set_decoded(hipStream_t s, const Buffers& b, uint32_t n, const int2* id_nrot_dev);
 void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
 void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);

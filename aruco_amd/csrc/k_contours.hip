@@ -238,7 +238,6 @@ constexpr int CK = 16;        // border steps between two checkpoints
 constexpr int LEASH_MAX = 96;     // most steps a candidate can get in the first pass (sizes the LDS checkpoint array)
 constexpr int LEASH_DEFAULT = 64; // a multiple of CK; ARUCOHIP_LEASH overrides for tuning
 constexpr int PROBE = 10;     // steps of the reverse probe: stays inside the 32x32 block loaded around the start
-constexpr uint32_t LONG_CAP = 1024;   // long walks per plane and kind (their checkpoint rings live in HBM)
 constexpr int GEN_MAX = 30;           // generations of the long walks (kernel launches after the first pass)
 constexpr int GEN_CNT_STRIDE = 32;    // uint32 words between two generation counters (one 128-byte line each)
 
@@ -549,8 +548,8 @@ __global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
         walk_generation<true>(a, blockIdx.x - a.gen_blocks, rows);
 }
 
-size_t walk_scratch_words(int nplanes, const DetectParams& p) {
-    return (size_t)((nplanes + 7) / 8) * 8 * 2 * LONG_CAP * ((p.max_contour + CK - 1) / CK);
+size_t walk_scratch_words(int nplanes, const DetectParams& p, uint32_t long_cap) {
+    return (size_t)((nplanes + 7) / 8) * 8 * 2 * long_cap * ((p.max_contour + CK - 1) / CK);
 }
 
 __global__ void snapshot_kernel(uint32_t* trig_cnt, int nplanes) {
@@ -568,11 +567,10 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     a.width = g.width, a.height = g.height, a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     a.scratch = b.walk_scratch, a.pool = b.pool, a.maxck = (p.max_contour + CK - 1) / CK;
     a.ring_cnt = b.ring_cnt, a.gen_cnt = b.gen_cnt;
-    // the buffer that used to hold the second pass's candidate list now holds the generation lists:
-    // [2 kinds][2 parities][gen_cap] states (16 B) followed by the ring ids (4 B)
-    const size_t bytes = (size_t)nplanes * b.cap_trig * sizeof(uint2);
-    a.long_cap = LONG_CAP;
-    a.gen_cap = (uint32_t)std::min<size_t>(bytes / (4 * 20), (size_t)nplanes * LONG_CAP);
+    // generation lists: [2 kinds][2 parities][gen_cap] states (16 B) followed by the ring ids (4 B); a list can never
+    // hold more walks than rings exist
+    a.long_cap = b.long_cap;
+    a.gen_cap = (uint32_t)((size_t)nplanes * b.long_cap);
     a.gen_state = (uint4*)b.gen_buf;
     a.gen_ring = (uint32_t*)(a.gen_state + 4 * (size_t)a.gen_cap);
     a.gen = 0, a.gen_steps = 0;

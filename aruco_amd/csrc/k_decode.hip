@@ -516,6 +516,7 @@ void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int n
     const int wave_blocks = (int)std::min<uint32_t>(b.cap_flat, (uint32_t)nframes * 48u);
     hipLaunchKernelGGL(homography_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
     hipLaunchKernelGGL(warp_hist_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
+    if (p.decoder == ARUCOHIP_DECODER_USER) return;   // the host callback decodes the patches (capi.hip: user_decode_stage)
     hipLaunchKernelGGL(otsu_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
     if (p.decoder == 1) {
         HrmArgs d{p.hrm_n, p.hrm_count, p.hrm_correction, p.hrm_codes};
@@ -523,6 +524,18 @@ void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int n
     } else {
         hipLaunchKernelGGL(cells_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
     }
+}
+
+// ids / rotations a host decoder returned for the first n entries of the flat candidate list
+__global__ void set_decoded_kernel(Cand* cands, int cap_cands, const uint32_t* cand_list, uint32_t n, const int2* dec) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = cand_list[i];
+    Cand* c = cands + (size_t)(e >> 16) * cap_cands + (e & 0xFFFFu);
+    c->id = dec[i].x, c->nrot = dec[i].y;
+}
+void launch_set_decoded(hipStream_t s, const Buffers& b, uint32_t n, const int2* dec) {
+    if (n) hipLaunchKernelGGL(set_decoded_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b.cands, b.cap_cands, b.cand_list, n, dec);
 }
 
 // MarkerDetector::warp as a stage entry point: one patch from one quad

@@ -9,7 +9,7 @@
 
 namespace ah {
 
-constexpr int MAXM = 256;
+constexpr int MAXM = 512;   // = the largest candidates_per_frame arucohip_create_ex accepts
 
 __device__ __forceinline__ float perimeter_f(const float* c) {
     float sum = 0;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
     }
     __syncthreads();
     const int nv = min(s_nvalid, MAXM);
+    if (lane == 0 && s_nvalid > MAXM) atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_MARKER_OVERFLOW);
     if (lane == 0) {
         for (int i = 0; i < nv - 1; i++) {
             if (s_id[i] == s_id[i + 1] && !s_rem[i + 1]) {
@@ -182,6 +183,7 @@ struct BoardArgs {
     CamModel cam;
     arucohip_board_t* out;
     float* prob;
+    uint32_t* counters;
 };
 
 __global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
@@ -204,7 +206,10 @@ __global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
                 }
             if (slot < 0) continue;
             nk++;
-            if (np + 4 > MAX_BOARD_POINTS) continue;
+            if (np + 4 > MAX_BOARD_POINTS) {   // more correspondences than the kernel holds: reported, never silent
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_MARKER_OVERFLOW);
+                continue;
+            }
             for (int p = 0; p < 4; p++, np++) {
                 s_img[2 * np] = M[i].corners[2 * p], s_img[2 * np + 1] = M[i].corners[2 * p + 1];
                 const float* q = a.obj + ((size_t)slot * 4 + p) * 3;
@@ -263,7 +268,7 @@ void launch_board_pose(hipStream_t s, int nframes, const Buffers& b, const int32
     BoardArgs a;
     a.markers = b.markers, a.nmarkers = b.nmarkers, a.cap_markers = b.cap_markers;
     a.ids = ids, a.obj = obj, a.nboard = nboard, a.info_type = info_type, a.marker_size = marker_size, a.repj_thres = repj_thres;
-    a.cam = cam, a.out = out, a.prob = prob;
+    a.cam = cam, a.out = out, a.prob = prob, a.counters = b.counters;
     hipLaunchKernelGGL(board_pose_kernel, dim3(nframes), dim3(64), 0, s, a);
 }
 

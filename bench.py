@@ -4,6 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work: a plain `python bench.py --gpus N` (no RANK / WORLD_SIZE in the environment) starts the N ranks itself
+through torch.distributed.run BEFORE anything in this process touches the GPU, waits for them and relays rank 0's JSON line.
+
 One "step" = one arucohip_detect_batch over `--batch` synthetic 1080p frames (config 2 of BASELINE.json: ~20 markers
 per frame, threshold + contours + decode + LINES refinement, no pose) that are already resident in HBM; results stay
 in HBM. With N > 1 every rank owns its own camera stream (seed 4711 + rank, frames sharded one stream per GPU, no
@@ -65,6 +68,76 @@ def cpu_baseline(frames_host, seconds_single=8.0, seconds_multi=12.0):
             "single_thread_fps": round(single, 2)}
 
 
+def launch_ranks(n):
+    """Plain `python bench.py --gpus N`: this process has not touched the GPU (no torch import yet). Start N fresh rank
+    processes with torch.distributed.run on 127.0.0.1, forward what they print (their one JSON line to stdout, everything
+    else to stderr) and return their exit code. Nothing is re-exec'ed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+def stub_main(args, rank, world):
+    """--stub: the launcher / rank plumbing without a GPU (CPU test of `--gpus N`): gloo, a fake step that produces marker
+    blocks, the same barrier + max-over-ranks timing and gather as the real run. Never a measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from aruco_amd import dist as adist
+    from aruco_amd.capi import MARKER_DTYPE
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B = min(args.batch, 8)
+    blocks = np.zeros((B, CAP), MARKER_DTYPE)
+    blocks["id"][:, 0] = rank
+    mt = torch.from_numpy(blocks.view(np.uint8).reshape(B, CAP * 96).copy())
+    ct = torch.ones(B, dtype=torch.int32)
+    gathered = None
+
+    def step():
+        time.sleep(0.002)
+        return adist.gather_marker_blocks(mt, ct, dst=0) if world > 1 else ([mt], [ct])
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = adist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    if rank == 0:
+        ranks_seen = sorted(int(np.frombuffer(m.numpy().tobytes(), MARKER_DTYPE)[0]["id"]) for m in gathered[0])
+        print(json.dumps({"metric": "frames/sec at %d\u00d7%d" % (W, H), "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "stub (launcher test, no GPU work)", "config": {"workload": "stub", "ranks_gathered": ranks_seen}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +151,14 @@ def main():
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
+
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank:
+        sys.exit(launch_ranks(args.gpus))     # before torch / HIP are touched in this process
+    if args.stub:
+        return stub_main(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     import numpy as np
     import torch
@@ -89,8 +169,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

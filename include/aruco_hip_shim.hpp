@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -270,6 +271,25 @@ inline void arucohip_ogre_pose_(const cv::Mat_<double>& Rvec, const cv::Mat_<dou
     arucohip_throw_(arucohip_ogre_pose(r, t, position, orientation), "OgreGetPoseParameters", nullptr);
 }
 
+// Process-wide handle for calls that have no detector object to hang on (Marker::calculateExtrinsics): created on first
+// use on device ARUCOHIP_DEVICE (default 0), shared under a mutex (a handle is not re-entrant), never destroyed — the HIP
+// runtime may already be gone when static destructors run.
+struct SharedHandle_ {
+    std::mutex mu;
+    arucohip_handle* h = nullptr;
+    static SharedHandle_& get() {
+        static SharedHandle_* s = new SharedHandle_();
+        return *s;
+    }
+    arucohip_handle* ensure() {   // call with mu held
+        if (!h) {
+            const char* e = std::getenv("ARUCOHIP_DEVICE");
+            arucohip_throw_(arucohip_create(nullptr, e ? std::atoi(e) : 0, 64, 64, 1, &h), "arucohip_create", nullptr);
+        }
+        return h;
+    }
+};
+
 class Marker : public std::vector<cv::Point2f> {
 public:
     int id;
@@ -301,7 +321,28 @@ public:
         float a2 = std::fabs((m[1].x - m[2].x) * (m[3].y - m[2].y) - (m[1].y - m[2].y) * (m[3].x - m[2].x));
         return (a2 + a1) / 2.f;
     }
-    // marker.cpp:112-124 — needs a detector handle for the device solvePnP; see MarkerDetector::calculateExtrinsics
+    // marker.h:77 / marker.cpp:85-90
+    void calculateExtrinsics(float markerSize, const CameraParameters& CP, bool setYPerpendicular = true) {
+        if (!CP.isValid()) arucohip_throw_(ARUCOHIP_E_INVALID, "!CP.isValid(): invalid camera parameters. It is not possible to calculate extrinsics", nullptr);
+        calculateExtrinsics(markerSize, CP.CameraMatrix, CP.Distorsion, setYPerpendicular);
+    }
+    // marker.h:85 / marker.cpp:112-124: solvePnP of the 4 corners against the marker's own square (device kernel behind
+    // arucohip_calculate_extrinsics, on the process-wide handle). MarkerDetector::calculateExtrinsics is the batched form.
+    void calculateExtrinsics(float markerSize, cv::Mat CameraMatrix, cv::Mat Distorsion = cv::Mat(), bool setYPerpendicular = true) {
+        if (!(markerSize > 0 && isValid())) arucohip_throw_(ARUCOHIP_E_INVALID, "invalid marker. It is not possible to calculate extrinsics", nullptr);
+        float K[9], d[8];
+        if (!mat_to_K_(CameraMatrix, K)) arucohip_throw_(ARUCOHIP_E_INVALID, "CameraMatrix is empty", nullptr);
+        const int nd = mat_to_dist_(Distorsion, d);
+        arucohip_marker_t m;
+        to_abi(&m);
+        SharedHandle_& sh = SharedHandle_::get();
+        std::lock_guard<std::mutex> lock(sh.mu);
+        arucohip_handle* h = sh.ensure();
+        arucohip_throw_(arucohip_calculate_extrinsics(h, &m, 1, K, nd ? d : nullptr, nd, markerSize, setYPerpendicular ? 1 : 0), "Marker::calculateExtrinsics", h);
+        Rvec = cv::Mat_<double>(3, 1), Tvec = cv::Mat_<double>(3, 1);
+        for (int k = 0; k < 3; k++) Rvec(k) = m.rvec[k], Tvec(k) = m.tvec[k];
+        ssize = markerSize;
+    }
     void glGetModelViewMatrix(double modelview_matrix[16]) const { arucohip_gl_modelview_(Rvec, Tvec, modelview_matrix); }              // marker.h:90
     void OgreGetPoseParameters(double position[3], double orientation[4]) const { arucohip_ogre_pose_(Rvec, Tvec, position, orientation); }  // marker.h:104
     friend bool operator<(const Marker& a, const Marker& b) { return a.id < b.id; }
@@ -498,12 +539,19 @@ public:
         bool hasK = mat_to_K_(camMatrix, K);
         int nd = mat_to_dist_(distCoeff, d);
         std::vector<arucohip_marker_t> out(256);
-        int n = 0;
-        int rc = input.type() == CV_8UC3
+        int n = 0, rc;
+        for (int attempt = 0;; attempt++) {
+            rc = input.type() == CV_8UC3
                      ? arucohip_detect_bgr(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
                                            setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n)
                      : arucohip_detect(h_, input.data, input.cols, input.rows, input.step, hasK ? K : nullptr, nd ? d : nullptr, nd, markerSizeMeters,
                                        setYPerpendicular ? 1 : 0, out.data(), (int)out.size(), &n);
+            // a cluttered frame can outgrow the device lists; the reference has no such limit, so the lists are doubled and the
+            // frame is detected again instead of failing
+            if (rc != ARUCOHIP_E_OVERFLOW || attempt >= 5) break;
+            grow_++;
+            recreate_();
+        }
         arucohip_throw_(rc, "MarkerDetector::detect", h_);
         detectedMarkers.clear();
         for (int i = 0; i < n; i++) detectedMarkers.push_back(Marker::from_abi(out[i]));
@@ -516,15 +564,18 @@ public:
         detect(input, detectedMarkers, camParams.CameraMatrix, camParams.Distorsion, markerSizeMeters, setYPerpendicular);
     }
 
-    // markerdetector.h:248: the two decoders of the library are accepted (they run on the device), other functions are not
-    void setMakerDetectorFunction(int (*markerdetector_func)(const cv::Mat& in, int& nRotations)) {
+    // markerdetector.h:78
+    typedef int (*MarkerdetectorFunc)(const cv::Mat& in, int& nRotations);
+    // markerdetector.h:243-245. The library's two decoders select the device kernels; any other function is called on the
+    // host with the canonical patch the device warped (contract: markerdetector.h:65-77), the pipeline continues on the device.
+    void setMakerDetectorFunction(MarkerdetectorFunc markerdetector_func) {
+        user_fn_ = nullptr, hrm_ = false;
         if (markerdetector_func == &HighlyReliableMarkers::detect)
             hrm_ = true;
-        else if (markerdetector_func == &FiducidalMarkers::detect)
-            hrm_ = false;
-        else
-            arucohip_throw_(ARUCOHIP_E_UNSUPPORTED, "setMakerDetectorFunction: only FiducidalMarkers::detect and HighlyReliableMarkers::detect", nullptr);
-        p_.decoder_kind = hrm_ ? ARUCOHIP_DECODER_HRM : ARUCOHIP_DECODER_FIDUCIAL_5X5;   // part of the parameter set from now on
+        else if (markerdetector_func != &FiducidalMarkers::detect)
+            user_fn_ = markerdetector_func;
+        if (!markerdetector_func) arucohip_throw_(ARUCOHIP_E_INVALID, "setMakerDetectorFunction: null function", nullptr);
+        p_.decoder_kind = user_fn_ ? ARUCOHIP_DECODER_USER : hrm_ ? ARUCOHIP_DECODER_HRM : ARUCOHIP_DECODER_FIDUCIAL_5X5;   // part of the parameter set from now on
         hrm_version_ = -1;
         if (h_) apply_decoder_();
     }
@@ -647,13 +698,25 @@ private:
         ensure_(w, hh);
     }
     void ensure_(int w, int hh) {
-        if (h_ && (size_t)w * hh <= (size_t)cap_w_ * cap_h_) return;
+        if (h_ && w <= cap_w_ && hh <= cap_h_) return;   // device arrays are sized per dimension
+        w = std::max(w, cap_w_), hh = std::max(hh, cap_h_);
         arucohip_destroy(h_);
         h_ = nullptr;
-        arucohip_throw_(arucohip_create(&p_, device_, w, hh, 1, &h_), "arucohip_create", nullptr);
+        arucohip_limits_t lim;
+        arucohip_default_limits(&lim, w, hh, 1);
+        lim.max_thres_planes = std::max(1, 2 * p_.thres_param1_range + 1);
+        // the reference has no list limits: after a device list overflow detect() retries with larger lists (grow_)
+        for (int g = 0; g < grow_; g++) {
+            lim.triggers_per_frame = std::min(lim.triggers_per_frame * 2, 1 << 22);
+            lim.contours_per_frame = std::min(lim.contours_per_frame * 2, 1 << 18);
+            lim.points_per_frame = std::min(lim.points_per_frame * 2, 1 << 24);
+            lim.long_walks_per_plane = std::min(lim.long_walks_per_plane * 2, 1 << 16);
+        }
+        lim.candidates_per_frame = 512, lim.markers_per_frame = 256;
+        arucohip_throw_(arucohip_create_ex(&p_, device_, &lim, &h_), "arucohip_create", nullptr);
         cap_w_ = w, cap_h_ = hh;
         hrm_version_ = -1;
-        if (hrm_) apply_decoder_();
+        if (hrm_ || user_fn_) apply_decoder_();
     }
     // HighlyReliableMarkers' static dictionary -> the handle (arucohip_set_dictionary), or back to the fiducial decoder
     void apply_decoder_() {
@@ -667,10 +730,22 @@ private:
             arucohip_throw_(arucohip_set_dictionary(h_, (int)s.D[0].n(), (int)codes.size(), codes.data(), s.D.tau0, s.rate), "loadDictionary", h_);
             hrm_version_ = s.version;
         }
+        arucohip_throw_(arucohip_set_decoder_callback(h_, user_fn_ ? &user_trampoline_ : nullptr, reinterpret_cast<void*>(user_fn_)), "setMakerDetectorFunction", h_);
         push_();
     }
+    // the C ABI's callback -> the reference's function type: a cv::Mat header over the patch, nRotations by reference
+    static int user_trampoline_(void* user, uint8_t* patch, int size, int* n_rotations) {
+        MarkerdetectorFunc fn = reinterpret_cast<MarkerdetectorFunc>(user);
+        cv::Mat in(size, size, CV_8UC1, patch);
+        int nrot = *n_rotations;
+        const int id = fn(in, nrot);
+        *n_rotations = nrot;
+        return id;
+    }
+    MarkerdetectorFunc user_fn_ = nullptr;
     arucohip_handle* h_;
     int device_, cap_w_, cap_h_;
+    int grow_ = 0;   // doublings of the device list limits after overflows
     arucohip_params_t p_;
     int speed_ = 0;
     bool hrm_ = false;
@@ -679,6 +754,53 @@ private:
     cv::Mat thres_;
     bool thres_valid_ = false, cand_valid_ = false;
     std::vector<std::vector<cv::Point2f> > candidates_;
+};
+
+// Frames sharded over the GPUs of the node behind one call (arucohip_mgpu_*). No reference counterpart: the
+// reference's frame loop (utils/aruco_test.cpp:140-160) calls one MarkerDetector per frame; with this helper the loop hands
+// over up to devices x framesPerDevice frames at once, frame f is detected on device f mod G and the markers come back in
+// frame order.
+class MultiGpuDetector {
+public:
+    MultiGpuDetector(const std::vector<int>& devices, int maxWidth, int maxHeight, int framesPerDevice, bool gatherOverXgmi = false) : m_(nullptr) {
+        arucohip_throw_(arucohip_mgpu_create(nullptr, devices.empty() ? nullptr : devices.data(), devices.empty() ? arucohip_mgpu_device_count() : (int)devices.size(),
+                                             maxWidth, maxHeight, framesPerDevice, 128, gatherOverXgmi ? ARUCOHIP_MGPU_GATHER_PEER : ARUCOHIP_MGPU_GATHER_HOST, &m_),
+                        "arucohip_mgpu_create", nullptr);
+    }
+    ~MultiGpuDetector() { arucohip_mgpu_destroy(m_); }
+    MultiGpuDetector(const MultiGpuDetector&) = delete;
+    MultiGpuDetector& operator=(const MultiGpuDetector&) = delete;
+    int devices() const { return arucohip_mgpu_size(m_); }
+    // equally sized 8-bit gray frames; same camera arguments as MarkerDetector::detect
+    void detect(const std::vector<cv::Mat>& frames, std::vector<std::vector<Marker> >& detectedMarkers, cv::Mat camMatrix = cv::Mat(),
+                cv::Mat distCoeff = cv::Mat(), float markerSizeMeters = -1, bool setYPerpendicular = false) {
+        detectedMarkers.assign(frames.size(), std::vector<Marker>());
+        if (frames.empty()) return;
+        const int w = frames[0].cols, h = frames[0].rows;
+        std::vector<unsigned char> packed((size_t)frames.size() * w * h);
+        for (size_t f = 0; f < frames.size(); f++) {
+            if (frames[f].type() != CV_8UC1 || frames[f].cols != w || frames[f].rows != h)
+                arucohip_throw_(ARUCOHIP_E_INVALID, "MultiGpuDetector::detect: equally sized CV_8UC1 frames", nullptr);
+            for (int r = 0; r < h; r++) std::memcpy(packed.data() + (f * h + r) * (size_t)w, frames[f].data + (size_t)r * frames[f].step, (size_t)w);
+        }
+        float K[9], d[8];
+        const bool hasK = mat_to_K_(camMatrix, K);
+        const int nd = mat_to_dist_(distCoeff, d);
+        std::vector<arucohip_marker_t> out(frames.size() * 128);
+        std::vector<int32_t> n(frames.size(), 0);
+        const int rc = arucohip_mgpu_detect_batch(m_, packed.data(), (int)frames.size(), w, h, (size_t)w, (size_t)w * h, hasK ? K : nullptr, nd ? d : nullptr, nd,
+                                                  markerSizeMeters, setYPerpendicular ? 1 : 0, out.data(), 128, n.data());
+        if (rc != ARUCOHIP_OK) throw cv::Exception(rc == ARUCOHIP_E_INVALID ? -215 : -2, std::string("MultiGpuDetector::detect: ") + arucohip_mgpu_last_error_string(m_)
+#if ARUCOHIP_HAVE_OPENCV
+                                                   , "arucohip", __FILE__, __LINE__
+#endif
+        );
+        for (size_t f = 0; f < frames.size(); f++)
+            for (int i = 0; i < n[f]; i++) detectedMarkers[f].push_back(Marker::from_abi(out[f * 128 + i]));
+    }
+
+private:
+    arucohip_mgpu* m_;
 };
 
 class BoardDetector {

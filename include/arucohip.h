@@ -28,7 +28,7 @@ enum {
     ARUCOHIP_OK = 0,
     ARUCOHIP_E_INVALID = 1,      /* bad argument: what the reference rejects with CV_Assert (markerdetector.cpp:644,685,1032-1034,1048) */
     ARUCOHIP_E_CAPACITY = 2,     /* output array too small; *n_out holds the required count */
-    ARUCOHIP_E_UNSUPPORTED = 3,  /* CANNY threshold, locked corners, user decoder callback: not on this path */
+    ARUCOHIP_E_UNSUPPORTED = 3,  /* a parameter value outside what the device kernels are built for (e.g. warp size > 128) */
     ARUCOHIP_E_HIP = 4,          /* HIP runtime failure, see arucohip_last_error_string */
     ARUCOHIP_E_OVERFLOW = 5,     /* an internal device list overflowed (raise limits with arucohip_create_ex) */
     ARUCOHIP_E_BOARD_CONFIG = 6  /* empty board configuration (boarddetector.cpp:93) */
@@ -41,7 +41,7 @@ enum { ARUCOHIP_CORNER_NONE = 0, ARUCOHIP_CORNER_HARRIS = 1, ARUCOHIP_CORNER_SUB
 /* BoardConfiguration::mInfoType (board.h:64) */
 enum { ARUCOHIP_BOARD_NONE = -1, ARUCOHIP_BOARD_PIX = 0, ARUCOHIP_BOARD_METERS = 1 };
 /* decoder behind MarkerDetector::setMakerDetectorFunction (markerdetector.h:243) */
-enum { ARUCOHIP_DECODER_FIDUCIAL_5X5 = 0, ARUCOHIP_DECODER_HRM = 1 };
+enum { ARUCOHIP_DECODER_FIDUCIAL_5X5 = 0, ARUCOHIP_DECODER_HRM = 1, ARUCOHIP_DECODER_USER = 2 };
 
 /* 1:1 image of MarkerDetector's private configuration members (markerdetector.h:283-306; defaults .cpp:235-249). */
 typedef struct arucohip_params {
@@ -55,7 +55,8 @@ typedef struct arucohip_params {
     float max_size;             /* _maxSize            default 0.5  */
     float border_dist;          /* _borderDistThres    default 0.025 */
     int32_t use_locked_corners; /* _useLockedCorners   default 0 (1 -> ARUCOHIP_E_UNSUPPORTED) */
-    int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5, or ARUCOHIP_DECODER_HRM after arucohip_set_dictionary */
+    int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5, ARUCOHIP_DECODER_HRM after
+                                   arucohip_set_dictionary, ARUCOHIP_DECODER_USER after arucohip_set_decoder_callback */
     int32_t reserved_;
 } arucohip_params_t;
 
@@ -88,6 +89,8 @@ typedef struct arucohip_limits {
     int32_t points_per_frame;      /* contour-point pool (average per frame) */
     int32_t candidates_per_frame;  /* quads per frame */
     int32_t markers_per_frame;     /* device-side marker slots per frame */
+    int32_t long_walks_per_plane;  /* borders followed beyond the first 64 steps, per threshold plane and kind (outer /
+                                      hole); each holds a checkpoint ring of max contour length / 16 words in HBM */
 } arucohip_limits_t;
 
 typedef struct arucohip_handle arucohip_handle;
@@ -140,6 +143,19 @@ int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes
  * the nearest-entry search it falls back to — the intended behaviour, identical whenever the ids are unique — is what runs
  * here for every n. */
 int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t* codes, int tau0, float correction_rate);
+
+/* SURVEY §8b, plugin boundary — MarkerDetector::setMakerDetectorFunction (src/markerdetector.h:243-245) with a function of
+ * the caller's own: typedef int (*MarkerdetectorFunc)(const cv::Mat& in, int& nRotations) (:78; contract :65-77: `in` is
+ * the square canonical view of a candidate, the return value is the marker id or -1, nRotations the number of 90-degree
+ * clockwise turns that bring the candidate to its canonical orientation). With params.decoder_kind =
+ * ARUCOHIP_DECODER_USER the device still warps every candidate (MarkerDetector::warp, :353), the size x size patches come
+ * back to the host, `fn` is called once per candidate in the reference's order (frame by frame, candidates in
+ * detectRectangles order, *n_rotations preset to 0) and the rest of the pipeline — corner refinement, rotation of the
+ * corners, sorting, duplicate and border filters, pose — continues on the device with the ids it returned. `patch` is a
+ * scratch copy the function may overwrite (FiducidalMarkers::detect thresholds its input in place, arucofidmarkers.cpp:446).
+ * A batch call then blocks until the decoders have run, also with out_on_device. fn = NULL removes the callback. */
+typedef int (*arucohip_decoder_fn)(void* user, uint8_t* patch, int size, int* n_rotations);
+int arucohip_set_decoder_callback(arucohip_handle* h, arucohip_decoder_fn fn, void* user);
 
 /* SURVEY §8 row f3 — frames with three interleaved 8-bit channels in B,G,R order (what cv::imread / cv::VideoCapture
  * deliver; row_stride >= 3*width): MarkerDetector::detect converts them with cv::cvtColor(CV_BGR2GRAY)
@@ -216,6 +232,36 @@ int arucohip_enable_timing(arucohip_handle* h, int on);
 /* Per-kernel average device time (ms per batch) since arucohip_enable_timing; names via arucohip_kernel_name. */
 int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap);
 const char* arucohip_kernel_name(int i);
+
+/* ---- Frame sharding over the GPUs of one node (no reference counterpart — the reference is single-process
+ * CPU code; the caller shape is the frame loop of utils/aruco_test.cpp:140-160 with one detector per GPU behind one call).
+ * Frames are independent units: frame f goes to device slot f mod G, there is no collective on the data path. The per-frame
+ * marker blocks {n, arucohip_marker_t[cap]} are gathered once per call: each slot copies its block to pinned host memory, or
+ * with ARUCOHIP_MGPU_GATHER_PEER device-to-device (xGMI) into one buffer on the first device that a single copy brings to
+ * the host. One host thread per slot keeps the devices busy concurrently. (Across PROCESSES, one rank per GPU, the same
+ * blocks are gathered with RCCL: bench.py / aruco_amd/dist.py.) */
+enum { ARUCOHIP_MGPU_GATHER_HOST = 0, ARUCOHIP_MGPU_GATHER_PEER = 1 };
+typedef struct arucohip_mgpu arucohip_mgpu;
+int arucohip_mgpu_device_count(void);
+/* devices: ndevices HIP device ids (NULL: 0..ndevices-1; an id may repeat, every slot gets its own handle and stream).
+ * Every slot takes up to max_frames_per_device frames per call; cap = marker slots per frame in the gathered blocks. */
+int arucohip_mgpu_create(const arucohip_params_t* params, const int* devices, int ndevices, int max_width, int max_height,
+                         int max_frames_per_device, int cap, int flags, arucohip_mgpu** out);
+void arucohip_mgpu_destroy(arucohip_mgpu* m);
+int arucohip_mgpu_size(const arucohip_mgpu* m);
+arucohip_handle* arucohip_mgpu_handle(arucohip_mgpu* m, int slot);   /* a slot's own handle (dictionary, callback, timing) */
+int arucohip_mgpu_set_params(arucohip_mgpu* m, const arucohip_params_t* p);
+const char* arucohip_mgpu_last_error_string(const arucohip_mgpu* m);
+/* nframes host frames (frame f at frames + f*frame_stride), frame f -> slot f mod G; out[f*cap ..], n_out[f] in frame order. */
+int arucohip_mgpu_detect_batch(arucohip_mgpu* m, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                               size_t frame_stride, const float* K, const float* dist, int ndist, float marker_size,
+                               int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out);
+/* One camera stream per slot, frames already resident in that slot's HBM (BASELINE config 5): frames_dev[g] = device pointer
+ * on slot g's device, nframes[g] <= max_frames_per_device. Results camera-major: frame j of slot g at index
+ * g*max_frames_per_device + j of out (x cap) and n_out. */
+int arucohip_mgpu_detect_streams(arucohip_mgpu* m, const uint8_t* const* frames_dev, const int* nframes, int width, int height,
+                                 size_t row_stride, size_t frame_stride, const float* K, const float* dist, int ndist,
+                                 float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out);
 
 /* ---- OpenGL / Ogre conversions of the pose results (host arithmetic, no handle, no device work).
  * GetGLModelViewMatrix (src/utils.cpp:32-69; Marker::glGetModelViewMatrix src/marker.h:90, Board:: src/board.h:109):

@@ -74,3 +74,23 @@ def test_shard_indices_cover_everything():
             assert allidx == list(range(n))
             sizes = [len(adist.shard_indices(n, r, w)) for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain invocation (no RANK / WORLD_SIZE): bench.py starts the two ranks itself
+    before touching the GPU and relays exactly one JSON line. Driven here with --stub (gloo, fake step) — the launcher,
+    rendezvous on 127.0.0.1, gather and max-over-ranks timing are the real code."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["config"]["ranks_gathered"] == [0, 1]
+    assert doc["value"] > 0 and doc["data"].startswith("stub")

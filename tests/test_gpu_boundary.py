@@ -1,0 +1,167 @@
+"""GPU tests of the C-ABI boundary rows added in round 2: the caller's own decoder (plugin boundary, reference
+src/markerdetector.h:65-78,243-245) and the batched / multi-device entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch  # noqa: F401
+    from aruco_amd import capi, synth
+
+    assert torch.cuda.is_available()
+    capi.load()
+    return {"capi": capi, "torch": torch, "synth": synth}
+
+
+WORDS = np.array([[1, 0, 0, 0, 0], [1, 0, 1, 1, 1], [0, 1, 0, 0, 1], [0, 1, 1, 1, 0]], np.int32)
+
+
+def numpy_5x5_decoder(patch):
+    """Host decoder written for this test (not the oracle): Otsu by exhaustive between-class variance, 7x7 cell votes,
+    four rotations against the Hamming words. Returns (id or -1, nRotations)."""
+    n = patch.shape[0]
+    hist = np.bincount(patch.reshape(-1), minlength=256).astype(np.float64)
+    p = hist / hist.sum()
+    q1 = np.cumsum(p)
+    m = np.cumsum(p * np.arange(256))
+    mu = m[-1]
+    q2 = 1.0 - q1
+    ok = (np.minimum(q1, q2) >= 1.1920929e-7) & (np.maximum(q1, q2) <= 1 - 1.1920929e-7)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sigma = np.where(ok, q1 * q2 * (m / q1 - (mu - m) / q2) ** 2, 0.0)
+    thr = int(np.argmax(sigma)) if sigma.max() > 0 else 0
+    sw = n // 7
+    cells = (patch[:7 * sw, :7 * sw] > thr).reshape(7, sw, 7, sw).sum(axis=(1, 3)) > (sw * sw) // 2
+    if cells[0].any() or cells[6].any() or cells[:, 0].any() or cells[:, 6].any():
+        return -1, 0
+    code = cells[1:6, 1:6].astype(np.int32)
+
+    def dist(c):
+        return int(sum(min(int((row != w).sum()) for w in WORDS) for row in c))
+
+    best, nrot, keep = dist(code), 0, code
+    cur = code
+    for r in range(1, 4):
+        cur = np.rot90(cur, -1)            # out(i, j) = in(n - j - 1, i)
+        d = dist(cur)
+        if d < best:
+            best, nrot, keep = d, r, cur
+    if best != 0:
+        return -1, nrot
+    ident = 0
+    for y in range(5):
+        ident = (ident << 2) | (int(keep[y, 1]) << 1) | int(keep[y, 3])
+    return ident, nrot
+
+
+@pytest.mark.parametrize("case", ["single", "board", "chessboard"])
+def test_user_decoder_callback_equals_device_decoder(env, case):
+    """arucohip_set_decoder_callback: device warps, host decodes, device continues; the marker bytes equal the device
+    decoder's."""
+    capi = env["capi"]
+    gray, doc = load_case(case)
+    intr = doc["intrinsics"]
+    h = capi.Handle(640, 480, max_batch=1)
+    try:
+        ref = h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        ncand_total = len(h.debug_candidates(0)[1])
+        calls = []
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int))
+
+        def cb(user, patch, size, nrot):
+            a = np.ctypeslib.as_array(patch, shape=(size, size))
+            ident, r = numpy_5x5_decoder(a.copy())
+            a[:] = 0                        # the patch is scratch: a decoder may destroy it
+            nrot[0] = r
+            calls.append(ident)
+            return ident
+
+        fn = FN(cb)
+        L = capi.load()
+        L.arucohip_set_decoder_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        p = h.get_params()
+        p.decoder_kind = 2
+        with pytest.raises(capi.ArucoHipError):      # USER without a callback is refused when a frame arrives
+            h.set_params(p)
+            h.detect(gray)
+        assert L.arucohip_set_decoder_callback(h.h, C.cast(fn, C.c_void_p), None) == 0
+        h.set_params(p)
+        got = h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        assert got.tobytes() == ref.tobytes()
+        assert len(calls) == ncand_total and sorted(i for i in calls if i >= 0) == sorted(int(m["id"]) for m in ref)
+        assert [int(m["id"]) for m in got] == [e["id"] for e in doc["markers"]]
+        # removing the callback restores the device decoder
+        assert L.arucohip_set_decoder_callback(h.h, None, None) == 0
+        assert h.get_params().decoder_kind == 0
+        assert h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0).tobytes() == ref.tobytes()
+    finally:
+        h.close()
+
+
+def test_user_decoder_on_a_batch(env):
+    capi, torch = env["capi"], env["torch"]
+    frames, truth = env["synth"].make_stream(3, width=1920, height=1080, seed=23, device="cuda")
+    fr = frames.cpu().numpy()
+    h = capi.Handle(1920, 1080, max_batch=3)
+    try:
+        ref = h.detect_batch_host(fr)
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int))
+
+        def cb(user, patch, size, nrot):
+            ident, r = numpy_5x5_decoder(np.ctypeslib.as_array(patch, shape=(size, size)))
+            nrot[0] = r
+            return ident
+
+        fn = FN(cb)
+        L = capi.load()
+        L.arucohip_set_decoder_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.arucohip_set_decoder_callback(h.h, C.cast(fn, C.c_void_p), None) == 0
+        p = h.get_params()
+        p.decoder_kind = 2
+        h.set_params(p)
+        got = h.detect_batch_host(fr)
+        assert sum(len(g) for g in got) >= 50
+        for a, b in zip(got, ref):
+            assert a.tobytes() == b.tobytes()
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_mgpu_sharding_equals_single_handle(env, flags):
+    """arucohip_mgpu_detect_batch / _detect_streams: frame f on slot f mod G, blocks gathered (host copy or device-to-device
+    into the first device). On this one-GPU box the slots are three handles on device 0 — the sharding, the strided
+    sub-batches, the ragged last round and the gather are the code that runs on G GPUs."""
+    capi, torch = env["capi"], env["torch"]
+    frames, truth = env["synth"].make_stream(7, width=1920, height=1080, seed=31, device="cuda")
+    fr = frames.cpu().numpy()
+    single = capi.Handle(1920, 1080, max_batch=7)
+    try:
+        ref = single.detect_batch_host(fr, cap=64)
+    finally:
+        single.close()
+    mg = capi.MultiGpu([0, 0, 0], 1920, 1080, frames_per_device=3, cap=64, flags=flags)
+    try:
+        assert capi.load().arucohip_mgpu_size(mg.m) == 3
+        got = mg.detect_batch_host(fr)                        # 7 frames over 3 slots: 3 + 2 + 2
+        assert len(got) == 7
+        for a, b in zip(got, ref):
+            assert a.tobytes() == b.tobytes()
+        assert sum(len(g) for g in got) >= 100
+        with pytest.raises(capi.ArucoHipError):               # more frames than slots x frames per slot
+            mg.detect_batch_host(np.zeros((10, 1080, 1920), np.uint8))
+        # camera streams resident per slot (config 5): slot g gets frames [2g, 2g+1], the last slot a single frame
+        ptrs = [frames[0].data_ptr(), frames[2].data_ptr(), frames[4].data_ptr()]
+        res = mg.detect_streams(ptrs, [2, 2, 1], 1920, 1080)
+        for g, cnt in enumerate([2, 2, 1]):
+            for j in range(cnt):
+                assert res[g][j].tobytes() == ref[2 * g + j].tobytes()
+    finally:
+        mg.close()

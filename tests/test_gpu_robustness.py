@@ -1,0 +1,114 @@
+"""GPU tests of the limits and failure paths: what the device lists and packed fields cannot hold is reported through
+the status code (never silently truncated, never out of bounds) and the shim path recovers the way the reference —
+which has no list limits — behaves."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch  # noqa: F401
+    from aruco_amd import capi
+    from oracle import orc
+
+    assert torch.cuda.is_available()
+    capi.load()
+    return {"capi": capi, "orc": orc, "torch": torch}
+
+
+def test_frame_wider_or_taller_than_the_handle_is_rejected(env):
+    """the geometry check is per dimension (tile rows, 14-bit checkpoint coordinates), not per area."""
+    capi = env["capi"]
+    h = capi.Handle(1920, 1080, max_batch=1)
+    try:
+        for (w, hh) in ((3840, 270), (32, 64800 // 4), (1921, 1080), (1920, 1081)):
+            g = np.zeros((hh, w), np.uint8)
+            with pytest.raises(capi.ArucoHipError) as e:
+                h.detect(g)
+            assert e.value.code == capi.E_INVALID, (w, hh)
+        # the same area in the handle's own shape is fine
+        assert len(h.detect(np.full((1080, 1920), 128, np.uint8))) == 0
+    finally:
+        h.close()
+    # handles whose raster index would not fit Quad::key are refused at creation
+    with pytest.raises(capi.ArucoHipError):
+        capi.Handle(16383, 16383, max_batch=1)
+
+
+def test_board_with_too_many_points_is_refused(env):
+    """arucohip_board_detect keeps obj + img + reprojection (7 floats per point) in an 8192-float scratch."""
+    capi = env["capi"]
+    h = capi.Handle(640, 480, max_batch=1)
+    try:
+        n = 300                                             # 1200 points: 5 * npts fits, 7 * npts does not
+        markers = np.zeros(n, capi.MARKER_DTYPE)
+        ids = np.arange(n, dtype=np.int32)
+        obj = np.zeros((n, 4, 3), np.float32)
+        for i in range(n):
+            x0, y0 = (i % 20) * 30.0, (i // 20) * 30.0
+            obj[i] = [[x0, y0, 0], [x0 + 20, y0, 0], [x0 + 20, y0 + 20, 0], [x0, y0 + 20, 0]]
+            markers[i]["id"] = i
+            markers[i]["corners"] = (obj[i, :, :2] + 10).reshape(-1)
+        K = [500, 0, 320, 0, 500, 240, 0, 0, 1]
+        with pytest.raises(capi.ArucoHipError) as e:
+            h.board_detect(markers, ids, obj, capi.BOARD_PIX, K=K, dist=[0, 0, 0, 0], marker_size=0.05, repj_err_thres=1.5)
+        assert e.value.code == capi.E_CAPACITY
+        # a board that fits, with a reprojection threshold nothing passes: no pose, no crash (the reference would throw)
+        res = h.board_detect(markers[:8], ids[:8], obj[:8], capi.BOARD_PIX, K=K, dist=[0, 0, 0, 0], marker_size=0.05, repj_err_thres=1e-9)
+        assert res["has_pose"] == 0 and len(res["markers"]) == 8
+    finally:
+        h.close()
+
+
+def _cluttered(rng, hgt, wid):
+    """Dense texture as a GRAY frame: smooth random blobs of two levels with fine noise: thousands of long borders."""
+    a = rng.randn(hgt // 12 + 2, wid // 12 + 2)
+    a = np.kron(a, np.ones((12, 12)))[:hgt, :wid]
+    for _ in range(3):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5
+    g = np.where(a > 0, 200, 60) + rng.randint(-3, 4, size=a.shape)
+    return np.clip(g, 0, 255).astype(np.uint8)
+
+
+def test_cluttered_frame_overflow_is_reported_not_silent(env):
+    """A cluttered 1080p frame on a handle with deliberately small lists: the out_on_device path reports the overflow
+    through arucohip_batch_status; with default lists the same frame equals the oracle."""
+    capi, orc, torch = env["capi"], env["orc"], env["torch"]
+    rng = np.random.RandomState(5)
+    g = _cluttered(rng, 1080, 1920)
+    lim = capi.Limits()
+    capi.load().arucohip_default_limits(C.byref(lim), 1920, 1080, 1)
+    lim.long_walks_per_plane = 64
+    lim.contours_per_frame = 64
+    small = capi.Handle(1920, 1080, max_batch=1, limits=lim)
+    try:
+        fr = torch.from_numpy(g).cuda()
+        out = torch.zeros((1, 64 * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        small.detect_batch_device(fr.data_ptr(), 1, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        with pytest.raises(capi.ArucoHipError) as e:
+            small.batch_status()
+        assert e.value.code == capi.E_OVERFLOW
+        with pytest.raises(capi.ArucoHipError) as e:       # host path: same condition as the return code
+            small.detect(g)
+        assert e.value.code == capi.E_OVERFLOW
+    finally:
+        small.close()
+    h = capi.Handle(1920, 1080, max_batch=1)
+    try:
+        h.detect(g)
+        ref = orc.find_contours(orc.adaptive_threshold(g, 7, 7.0))
+        ref = [c for c in ref if 307 < len(c["pts"]) < 3840]
+        got = h.debug_contours(0)
+        assert len(ref) > 100                              # it is cluttered
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert a["hole"] == b["hole"] and np.array_equal(a["pts"], b["pts"])
+    finally:
+        h.close()

@@ -107,3 +107,32 @@ def test_shim_hrm(tmp_path):
         assert np.max(np.abs(g["corners"] - np.array(e["corners"]))) < 1e-3
         assert rel_err(g["rvec"], e["Rvec"]) < 1e-4 and rel_err(g["tvec"], e["Tvec"]) < 1e-4
     assert "fiducial=" in r.stdout
+
+
+def test_shim_member_extrinsics_and_user_decoder(tmp_path):
+    """Round 2 boundary rows: Marker::calculateExtrinsics (reference src/marker.h:77,85) against the golden poses of
+    testdata/single, and setMakerDetectorFunction with the caller's own host decoder (src/markerdetector.h:65-78) against
+    the device decoder — through a C++ caller of the shim."""
+    from aruco_amd import build_library
+    build_library()
+    doc = json.load(open(os.path.join(GOLDEN, "single.json")))
+    intr = tmp_path / "intr.txt"
+    write_intrinsics(intr, doc["intrinsics"])
+    exe = tmp_path / "shim_callbacks"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_callbacks.cpp"), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), os.path.join(GOLDEN, "single.pgm"), str(intr)], stdout=subprocess.PIPE, text=True, check=True)
+    lines = r.stdout.splitlines()
+    exp = doc["markers"]
+    got = parse_markers("\n".join(l[5:] for l in lines if l.startswith("extr ")))
+    assert [g["id"] for g in got] == [e["id"] for e in exp]
+    for g, e in zip(got, exp):
+        assert rel_err(g["rvec"], e["Rvec"]) < 1e-4 and rel_err(g["tvec"], e["Tvec"]) < 1e-4   # north_star tolerance
+    assert "invalid marker rejected" in r.stdout
+    dev = [l[4:] for l in lines if l.startswith("dev ")]
+    usr = [l[4:] for l in lines if l.startswith("usr ")]
+    assert len(dev) == len(exp) and dev == usr            # identical ids, corner order, corners and poses
+    m = re.search(r"decoder calls=(\d+) candidates=(\d+)", r.stdout)
+    assert m and int(m.group(1)) == len(exp) + int(m.group(2))   # one call per candidate of detectRectangles
+    assert "after reset: calls 0 markers %d" % len(exp) in r.stdout
