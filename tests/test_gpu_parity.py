@@ -417,7 +417,7 @@ def test_hrm_decoder(env):
     capi, orc = env["capi"], env["orc"]
     gray, doc = load_case("hrm")
     intr, st, dic = doc["intrinsics"], doc["settings"], doc["dictionary"]
-    h = capi.Handle(640, 480, max_batch=2)
+    h = capi.Handle(640, 640, max_batch=2)   # also takes the rotated 480x640 frame below (limits are per dimension)
     try:
         p = h.get_params()
         p.thres_param1, p.thres_param2, p.min_size, p.max_size, p.warp_size = st["thres_param1"], st["thres_param2"], st["min_size"], st["max_size"], st["warp_size"]

@@ -54,7 +54,8 @@ def test_board_with_too_many_points_is_refused(env):
             x0, y0 = (i % 20) * 30.0, (i // 20) * 30.0
             obj[i] = [[x0, y0, 0], [x0 + 20, y0, 0], [x0 + 20, y0 + 20, 0], [x0, y0 + 20, 0]]
             markers[i]["id"] = i
-            markers[i]["corners"] = (obj[i, :, :2] + 10).reshape(-1)
+            # not an exact image of the plane: every point keeps a reprojection error far above 1e-9 px
+            markers[i]["corners"] = (obj[i, :, :2] + 10 + np.random.RandomState(i).uniform(-0.4, 0.4, (4, 2))).reshape(-1)
         K = [500, 0, 320, 0, 500, 240, 0, 0, 1]
         with pytest.raises(capi.ArucoHipError) as e:
             h.board_detect(markers, ids, obj, capi.BOARD_PIX, K=K, dist=[0, 0, 0, 0], marker_size=0.05, repj_err_thres=1.5)
