@@ -68,6 +68,7 @@ SYMBOLS = [
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
     "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray", "arucohip_set_dictionary",
     "arucohip_set_decoder_callback",
+    "arucohip_set_pipeline_depth", "arucohip_detect_batch_submit", "arucohip_detect_batch_wait",
     "arucohip_mgpu_device_count", "arucohip_mgpu_create", "arucohip_mgpu_destroy", "arucohip_mgpu_size", "arucohip_mgpu_handle",
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
 ]
@@ -135,6 +136,9 @@ def load():
     L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
     L.arucohip_ogre_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
     L.arucohip_set_decoder_callback.argtypes = [vp, vp, vp]
+    L.arucohip_set_pipeline_depth.argtypes = [vp, i]
+    L.arucohip_detect_batch_submit.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i, vp]
+    L.arucohip_detect_batch_wait.argtypes = [vp, i]
     L.arucohip_mgpu_create.argtypes = [vp, vp, i, i, i, i, i, i, vp]
     L.arucohip_mgpu_destroy.argtypes = [vp]
     L.arucohip_mgpu_destroy.restype = None
@@ -300,6 +304,35 @@ class Handle:
         self._chk(self.L.arucohip_detect_batch(self.h, C.c_void_p(frames_host_ptr), nframes, width, height, width, width * height, 0,
                                                _ptr(Ka), _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
                                                C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1))
+
+    # ---- batches in flight
+    def set_pipeline_depth(self, depth):
+        self._chk(self.L.arucohip_set_pipeline_depth(self.h, int(depth)))
+
+    def submit_device(self, frames_ptr, nframes, width, height, out_ptr, cap, n_out_ptr, K=None, dist=None, marker_size=-1.0, y_perp=False,
+                      frames_on_device=True):
+        """arucohip_detect_batch_submit with results left on the device (frames device-resident, or in pinned host memory with
+        frames_on_device=False); returns the ticket."""
+        Ka, da = _f32(K), _f32(dist)
+        t = C.c_int(-1)
+        self._chk(self.L.arucohip_detect_batch_submit(self.h, C.c_void_p(frames_ptr), nframes, width, height, width, width * height,
+                                                      int(bool(frames_on_device)), _ptr(Ka),
+                                                      _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
+                                                      C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1, C.byref(t)))
+        return t.value
+
+    def submit_host(self, frames, out, n, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        """Host frames [n][H][W] and host result arrays (out: [n][cap] MARKER_DTYPE, n: int32[n]) that must stay alive
+        until wait(ticket)."""
+        nf, h, w = frames.shape
+        Ka, da = _f32(K), _f32(dist)
+        t = C.c_int(-1)
+        self._chk(self.L.arucohip_detect_batch_submit(self.h, _ptr(frames), nf, w, h, w, w * h, 0, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                                      float(marker_size), int(bool(y_perp)), _ptr(out), out.shape[1], _ptr(n), 0, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, allow=()):
+        return self._chk(self.L.arucohip_detect_batch_wait(self.h, int(ticket)), allow)
 
     def batch_status(self):
         return self._chk(self.L.arucohip_batch_status(self.h))

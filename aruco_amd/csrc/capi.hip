@@ -84,8 +84,24 @@ struct arucohip_handle {
     hipEvent_t ev_thr = nullptr;         // this worker's threshold kernel has finished (staggers the chunks, see detect_batch)
     hipEvent_t wait_thr = nullptr;       // set by detect_batch: event the next threshold kernel waits for
     int last_chunks = 1, last_per = 0;   // chunks and frames per chunk of the last batch
+    // Batches in flight (arucohip_set_pipeline_depth / _submit / _wait): every pipeline lane is a complete worker (own
+    // buffers, own stream); ticket t runs on lane t mod depth, so the latency-bound tail of batch t (border following,
+    // decoding) overlaps the bandwidth-bound head of batch t+1.
+    std::vector<arucohip_handle*> lanes;
+    int next_ticket = 0;
+    arucohip_handle* cur = nullptr;      // lane whose results the getters / board pose address (last waited ticket)
+    hipEvent_t ev_submit = nullptr;
+    struct Pending {
+        bool active = false;
+        int ticket = -1, nframes = 0, cap = 0, out_on_device = 0;
+        arucohip_marker_t* out = nullptr;
+        int32_t* n_out = nullptr;
+    } pend;
     std::string err;
 };
+
+// the worker that holds the results of the last completed batch
+static arucohip_handle* active(arucohip_handle* h) { return (h && h->cur) ? h->cur : h; }
 
 // worker that holds frame `frame` of the last batch (and the frame's index inside that worker)
 static arucohip_handle* route(arucohip_handle* h, int frame, int* local) {
@@ -166,6 +182,9 @@ static void free_all(arucohip_handle* h) {
     hipSetDevice(h->device);
     for (auto* k : h->kids) arucohip_destroy(k);
     h->kids.clear();
+    for (auto* l : h->lanes) arucohip_destroy(l);
+    h->lanes.clear();
+    if (h->ev_submit) hipEventDestroy(h->ev_submit);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_thr) hipEventDestroy(h->ev_thr);
     if (h->ev_wfork) hipEventDestroy(h->ev_wfork);
@@ -340,6 +359,10 @@ int arucohip_set_params(arucohip_handle* h, const arucohip_params_t* p) {
         return fail(h, ARUCOHIP_E_INVALID, "threshold range exceeds the planes this handle was created with");
     h->params = *p;
     for (auto* k : h->kids) k->params = *p;
+    for (auto* l : h->lanes) {
+        l->params = *p;
+        for (auto* k : l->kids) k->params = *p;
+    }
     return ARUCOHIP_OK;
 }
 
@@ -370,6 +393,7 @@ int arucohip_enable_timing(arucohip_handle* h, int on) {
     h->timing = on != 0;
     h->tsets = 0;
     for (auto* k : h->kids) k->timing = h->timing, k->tsets = 0;
+    for (auto* l : h->lanes) arucohip_enable_timing(l, on);
     return ARUCOHIP_OK;
 }
 // synchronises the stream and averages the per-kernel event intervals of the batches since enable/reset
@@ -391,6 +415,10 @@ static void collect_times(arucohip_handle* h) {
     };
     add(h);
     for (auto* k : h->kids) add(k);
+    for (auto* l : h->lanes) {
+        add(l);
+        for (auto* k : l->kids) add(k);
+    }
     if (total > 0)
         for (int k = 0; k < K_COUNT; k++) h->kernel_ms[k] /= total;
 }
@@ -758,9 +786,24 @@ static int join_workers(arucohip_handle* h, int chunks) {
     return ARUCOHIP_OK;
 }
 
+// the batch's stream has been filled: wait for it and copy every chunk's markers from the pinned staging to the caller
+static int collect_batch_host(arucohip_handle* h, int nframes, arucohip_marker_t* out, int cap, int32_t* n_out) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int chunks = std::max(h->last_chunks, 1), per = chunks > 1 ? h->last_per : nframes;
+    int ret = ARUCOHIP_OK;
+    for (int c = 0; c < chunks; c++) {
+        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
+        const int off = c * per, cnt = std::min(per, nframes - off);
+        if (cnt <= 0) break;
+        int r = chunk_collect_host(h, w, cnt, out + (size_t)off * cap, cap, n_out + off);
+        if (ret == ARUCOHIP_OK) ret = r;
+    }
+    return ret;
+}
+
 static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
                              int frames_on_device, int channels, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
-                             arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device) {
+                             arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device, bool defer = false) {
     if (!h || !frames || !n_out || (cap > 0 && !out) || cap < 0) return ARUCOHIP_E_INVALID;
     int rc = check_geometry(h, nframes, W, H, row_stride, channels);
     if (rc) return rc;
@@ -797,16 +840,8 @@ static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nfra
         }
     }
     if ((rc = join_workers(h, chunks))) return rc;
-    if (out_on_device) return ARUCOHIP_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    int ret = ARUCOHIP_OK;
-    for (int c = 0; c < chunks; c++) {
-        arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
-        const int off = c * per, cnt = std::min(per, nframes - off);
-        int r = chunk_collect_host(h, w, cnt, out + (size_t)off * cap, cap, n_out + off);
-        if (ret == ARUCOHIP_OK) ret = r;
-    }
-    return ret;
+    if (out_on_device || defer) return ARUCOHIP_OK;
+    return collect_batch_host(h, nframes, out, cap, n_out);
 }
 
 int arucohip_detect_batch(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
@@ -860,6 +895,10 @@ int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t
         int rc = arucohip_set_dictionary(k, n, count, codes, tau0, correction_rate);
         if (rc) return rc;
     }
+    for (auto* l : h->lanes) {
+        int rc = arucohip_set_dictionary(l, n, count, codes, tau0, correction_rate);
+        if (rc) return rc;
+    }
     return ARUCOHIP_OK;
 }
 
@@ -867,6 +906,7 @@ int arucohip_set_decoder_callback(arucohip_handle* h, arucohip_decoder_fn fn, vo
     if (!h) return ARUCOHIP_E_INVALID;
     h->decoder_fn = fn, h->decoder_user = user;
     for (auto* k : h->kids) k->decoder_fn = fn, k->decoder_user = user;
+    for (auto* l : h->lanes) arucohip_set_decoder_callback(l, fn, user);
     if (!fn && h->params.decoder_kind == ARUCOHIP_DECODER_USER) {
         h->params.decoder_kind = ARUCOHIP_DECODER_FIDUCIAL_5X5;
         for (auto* k : h->kids) k->params.decoder_kind = ARUCOHIP_DECODER_FIDUCIAL_5X5;
@@ -890,6 +930,7 @@ int arucohip_batch_status(arucohip_handle* h) {
 
 int arucohip_batch_chunks(arucohip_handle* h, int* frames_per_chunk) {
     if (!h) return 0;
+    h = active(h);
     if (frames_per_chunk) *frames_per_chunk = h->last_chunks > 1 ? h->last_per : h->last_frames;
     return std::max(h->last_chunks, 1);
 }
@@ -904,6 +945,7 @@ int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int W, int H, size_
 
 int arucohip_get_thresholded(arucohip_handle* h0, int frame, uint8_t* dst) {
     if (!h0 || !dst || frame < 0) return ARUCOHIP_E_INVALID;
+    h0 = active(h0);
     arucohip_handle* h = route(h0, frame, &frame);
     if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -916,6 +958,7 @@ int arucohip_get_thresholded(arucohip_handle* h0, int frame, uint8_t* dst) {
 
 static int fetch_cands(arucohip_handle* h0, int frame, std::vector<Cand>* v) {
     if (!h0 || frame < 0) return ARUCOHIP_E_INVALID;
+    h0 = active(h0);
     arucohip_handle* h = route(h0, frame, &frame);
     if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -965,6 +1008,7 @@ int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int3
 // contours of one frame in reference (RETR_LIST) order: planes ascending, raster key descending
 static int fetch_contours(arucohip_handle* h0, int frame, std::vector<ContourDesc>* out, arucohip_handle** owner = nullptr) {
     if (!h0 || frame < 0) return ARUCOHIP_E_INVALID;
+    h0 = active(h0);
     arucohip_handle* h = route(h0, frame, &frame);
     if (owner) *owner = h;
     if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
@@ -1023,6 +1067,7 @@ int arucohip_debug_contour(arucohip_handle* h0, int frame, int index, int* is_ho
 
 int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
     if (!h || !out8) return ARUCOHIP_E_INVALID;
+    h = active(h);
     HIPCHK(h, hipSetDevice(h->device));
     uint64_t acc[CNT_FIXED] = {};
     uint64_t ntrig = 0, nraw = 0;
@@ -1139,6 +1184,7 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
                                 const float* dist, int ndist, float marker_size, float repj_err_thres, int y_perp, arucohip_board_t* out, float* prob) {
     if (!h || !out || !prob) return ARUCOHIP_E_INVALID;
     if (nboard <= 0 || !ids || !obj) return fail(h, ARUCOHIP_E_BOARD_CONFIG, "invalid BoardConfig that is empty");
+    h = active(h);   // with batches in flight: the lane of the last ticket waited for
     const int chunks = std::max(h->last_chunks, 1), per = chunks > 1 ? h->last_per : h->last_frames;
     int have = 0;
     for (int c = 0; c < chunks; c++) have += (c == 0 ? h : h->kids[c - 1])->last_frames;
@@ -1290,6 +1336,77 @@ int arucohip_board_detect(arucohip_handle* h, const arucohip_marker_t* markers, 
     for (int k = 0; k < 3; k++) out->rvec[k] = rt[k], out->tvec[k] = rt[3 + k];
     *prob = float(nb) / float(nboard);
     return ARUCOHIP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Batches in flight. No reference counterpart (MarkerDetector::detect is synchronous); this is how a stream of batches
+// keeps the GPU busy: the tail of a batch is a chain of dependent border steps that a handful of wavefronts work on, the
+// head of the next batch is a streaming kernel that wants the whole chip.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int arucohip_set_pipeline_depth(arucohip_handle* h, int depth) {
+    if (!h || depth < 0 || depth > 8) return ARUCOHIP_E_INVALID;
+    for (auto* l : h->lanes)
+        if (l->pend.active) return fail(h, ARUCOHIP_E_INVALID, "a submitted batch has not been waited for");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (auto* l : h->lanes) arucohip_destroy(l);
+    h->lanes.clear();
+    h->cur = nullptr, h->next_ticket = 0;
+    if (depth == 0) return ARUCOHIP_OK;
+    if (!h->ev_submit) HIPCHK(h, hipEventCreateWithFlags(&h->ev_submit, hipEventDisableTiming));
+    for (int i = 0; i < depth; i++) {
+        arucohip_handle* l = nullptr;
+        int rc = arucohip_create_ex(&h->params, h->device, &h->lim, &l);
+        if (rc != ARUCOHIP_OK) return fail(h, rc, "creating a pipeline lane failed");
+        l->decoder_fn = h->decoder_fn, l->decoder_user = h->decoder_user;
+        for (auto* k : l->kids) k->decoder_fn = h->decoder_fn, k->decoder_user = h->decoder_user;
+        l->timing = h->timing;
+        h->lanes.push_back(l);
+        if (h->d_hrm && h->hrm_count > 0) {
+            std::vector<uint64_t> codes(h->hrm_count);
+            HIPCHK(h, hipMemcpy(codes.data(), h->d_hrm, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            if ((rc = arucohip_set_dictionary(l, h->hrm_n, h->hrm_count, codes.data(), h->hrm_tau0, h->hrm_rate))) return rc;
+        }
+    }
+    return ARUCOHIP_OK;
+}
+
+int arucohip_detect_batch_submit(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                                 int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                                 arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device, int* ticket) {
+    if (!h || !ticket) return ARUCOHIP_E_INVALID;
+    if (h->lanes.empty()) return fail(h, ARUCOHIP_E_INVALID, "arucohip_set_pipeline_depth first");
+    arucohip_handle* l = h->lanes[h->next_ticket % (int)h->lanes.size()];
+    if (l->pend.active) return fail(h, ARUCOHIP_E_CAPACITY, "pipeline full: wait for the oldest ticket first");
+    HIPCHK(h, hipSetDevice(h->device));
+    // what the caller's stream has queued so far (the frames) is visible to the lane
+    HIPCHK(h, hipEventRecord(h->ev_submit, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(l->stream, h->ev_submit, 0));
+    int rc = detect_batch_impl(l, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, 1, K, dist, ndist, marker_size, y_perp, out, cap, n_out,
+                               out_on_device, true);
+    if (rc) {
+        h->err = l->err;
+        return rc;
+    }
+    l->pend.active = true, l->pend.ticket = h->next_ticket, l->pend.nframes = nframes, l->pend.cap = cap, l->pend.out_on_device = out_on_device;
+    l->pend.out = out, l->pend.n_out = n_out;
+    *ticket = h->next_ticket++;
+    return ARUCOHIP_OK;
+}
+
+int arucohip_detect_batch_wait(arucohip_handle* h, int ticket) {
+    if (!h || h->lanes.empty() || ticket < 0) return ARUCOHIP_E_INVALID;
+    arucohip_handle* l = h->lanes[ticket % (int)h->lanes.size()];
+    if (!l->pend.active || l->pend.ticket != ticket) return fail(h, ARUCOHIP_E_INVALID, "no such batch in flight");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = l->pend.out_on_device ? arucohip_batch_status(l) : collect_batch_host(l, l->pend.nframes, l->pend.out, l->pend.cap, l->pend.n_out);
+    l->pend.active = false;
+    h->cur = l;
+    if (rc) h->err = l->err;
+    return rc;
 }
 
 }  // extern "C"

@@ -150,6 +150,8 @@ def main():
                     help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
@@ -211,8 +213,13 @@ def main():
     stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream shared by the library, its events and RCCL
     torch.cuda.set_stream(stream)
     handle.set_stream(stream.cuda_stream)
-    out = torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev)
-    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    depth = max(1, args.depth)
+    outs = [torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
+    out, cnt = outs[0], cnts[0]
+    if depth > 1:
+        handle.set_pipeline_depth(depth)      # `depth` complete workers: batch i+1's threshold runs under batch i's border following
+    tickets = [None] * depth
     K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1] if args.pose else None
     dcoef = [-0.10, 0.02, 1e-3, -5e-4, 0] if args.pose else None
     msize = 0.05 if args.pose else -1.0
@@ -220,23 +227,47 @@ def main():
 
     boards = []
 
-    def step(i):
-        off = (i % nwin) * B
-        if frames_host is not None:   # H2D of the batch is part of the step
-            handle.detect_batch_mixed(frames_host[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
-                                      marker_size=msize)
-        else:
-            handle.detect_batch_device(frames[off].data_ptr(), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef,
-                                       marker_size=msize)
+    last = {"slot": 0}
+
+    def finish(slot):
+        """The batch that owns result slot `slot` is complete: board poses of its frames (config 4) and the gather (N > 1)."""
+        if depth > 1:
+            handle.wait(tickets[slot])          # raises on any device-side list overflow of that batch
+            tickets[slot] = None
+        last["slot"] = slot
         if board is not None:
             boards[:] = handle.board_detect_batch(B, board["ids"], board["obj"], board["info_type"], board["K"], [0.0] * 5, 0.039)
         if world > 1:
-            return adist.gather_marker_blocks(out, cnt, dst=0)
-        return None
+            adist.gather_marker_blocks(outs[slot], cnts[slot], dst=0)
+
+    def step(i):
+        off = (i % nwin) * B
+        slot = i % depth
+        src = frames_host[off].data_ptr() if frames_host is not None else frames[off].data_ptr()   # host frames: H2D is part of the step
+        if depth > 1:
+            if tickets[slot] is not None:
+                finish(slot)                    # the batch submitted `depth` steps ago frees its result arrays
+            tickets[slot] = handle.submit_device(src, B, W, H, outs[slot].data_ptr(), CAP, cnts[slot].data_ptr(), K=K, dist=dcoef, marker_size=msize,
+                                                 frames_on_device=frames_host is None)
+            return
+        if frames_host is not None:
+            handle.detect_batch_mixed(src, B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+        else:
+            handle.detect_batch_device(src, B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+        finish(0)
+
+    def drain(nsteps):
+        """every batch still in flight completes (oldest first)"""
+        if depth > 1:
+            for j in range(max(0, nsteps - depth), nsteps):
+                if tickets[j % depth] is not None:
+                    finish(j % depth)
 
     for i in range(args.warmup):
         step(i)
-    handle.batch_status()
+    drain(args.warmup)
+    if depth == 1:
+        handle.batch_status()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,19 +275,21 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain(args.steps)                           # all K batches are complete inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    handle.batch_status()                       # raises on any device-side list overflow
+    if depth == 1:
+        handle.batch_status()                   # raises on any device-side list overflow
     elapsed = adist.max_over_ranks(elapsed, dev)
     ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams over the timed steps
     chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
     handle.enable_timing(False)
 
     # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
-    n_host = cnt.cpu().numpy()
-    arr = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAP)
+    n_host = cnts[last["slot"]].cpu().numpy()
+    arr = np.frombuffer(outs[last["slot"]].cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAP)
     off = ((args.steps - 1) % nwin) * B
     found = 0
     for f in range(B):
@@ -295,7 +328,7 @@ def main():
                                     + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
                                    + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else ""),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
-                       "markers_detected_per_frame": round(found / B, 2), "parallelism": "frames sharded 1 stream/GPU"
+                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth, "parallelism": "frames sharded 1 stream/GPU"
                        + (", RCCL gather of marker blocks per step" if world > 1 else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),

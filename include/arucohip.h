@@ -178,6 +178,23 @@ int arucohip_batch_status(arucohip_handle* h);
  * last batch and, if not NULL, the frames per chunk — every kernel launch covers one chunk. No reference counterpart. */
 int arucohip_batch_chunks(arucohip_handle* h, int* frames_per_chunk);
 
+/* Batches in flight (no reference counterpart: MarkerDetector::detect is synchronous). The tail of a batch — border
+ * following of the longest contours, decoding — is latency bound and leaves most of the chip idle, the head of the next
+ * batch is a streaming kernel: with depth >= 2 a stream of batches overlaps them. arucohip_set_pipeline_depth creates
+ * `depth` complete workers (own buffers, own stream; 0 removes them); arucohip_detect_batch_submit takes the arguments
+ * of arucohip_detect_batch, enqueues the batch on worker ticket mod depth behind everything queued on the handle's stream so
+ * far and returns at once; arucohip_detect_batch_wait(ticket) returns when that batch is complete (its status code: overflow /
+ * capacity conditions as arucohip_detect_batch / arucohip_batch_status would report them), host outputs are filled then.
+ * At most `depth` tickets can be outstanding (ARUCOHIP_E_CAPACITY otherwise); getters and arucohip_board_detect_batch
+ * address the batch of the last ticket waited for. Input frames and output arrays of a ticket must stay untouched until
+ * its wait returns. */
+int arucohip_set_pipeline_depth(arucohip_handle* h, int depth);
+int arucohip_detect_batch_submit(arucohip_handle* h, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                                 size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
+                                 float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
+                                 int out_on_device, int* ticket);
+int arucohip_detect_batch_wait(arucohip_handle* h, int ticket);
+
 /* MarkerDetector::getThresholdedImage (markerdetector.h:183): thresholded image of frame `frame` of the last call
  * (the middle one when thres_param1_range > 0), copied to host `dst` (width*height bytes, tightly packed). */
 int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst);

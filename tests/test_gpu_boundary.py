@@ -165,3 +165,43 @@ def test_mgpu_sharding_equals_single_handle(env, flags):
                 assert res[g][j].tobytes() == ref[2 * g + j].tobytes()
     finally:
         mg.close()
+
+
+def test_batches_in_flight_equal_synchronous_batches(env):
+    """arucohip_set_pipeline_depth / _submit / _wait: three batches on two pipeline lanes (host frames, host results) give
+    the bytes of three synchronous arucohip_detect_batch calls; a third outstanding ticket is refused; the getters address
+    the last batch waited for."""
+    capi = env["capi"]
+    frames, _ = env["synth"].make_stream(6, width=1920, height=1080, seed=41, device="cuda")
+    fr = frames.cpu().numpy()
+    K, dist = [1400, 0, 960, 0, 1400, 540, 0, 0, 1], [-0.1, 0.02, 1e-3, -5e-4, 0]
+    h = capi.Handle(1920, 1080, max_batch=2)
+    try:
+        ref = [h.detect_batch_host(fr[2 * b:2 * b + 2], K=K, dist=dist, marker_size=0.05, cap=64) for b in range(3)]
+        with pytest.raises(capi.ArucoHipError):          # no lanes yet
+            h.submit_host(fr[0:2], np.zeros((2, 64), capi.MARKER_DTYPE), np.zeros(2, np.int32))
+        h.set_pipeline_depth(2)
+        outs = [np.zeros((2, 64), capi.MARKER_DTYPE) for _ in range(3)]
+        ns = [np.zeros(2, np.int32) for _ in range(3)]
+        batches = [np.ascontiguousarray(fr[2 * b:2 * b + 2]) for b in range(3)]
+        t0 = h.submit_host(batches[0], outs[0], ns[0], K=K, dist=dist, marker_size=0.05)
+        t1 = h.submit_host(batches[1], outs[1], ns[1], K=K, dist=dist, marker_size=0.05)
+        with pytest.raises(capi.ArucoHipError) as e:     # both lanes busy
+            h.submit_host(batches[2], outs[2], ns[2], K=K, dist=dist, marker_size=0.05)
+        assert e.value.code == capi.E_CAPACITY
+        h.wait(t0)
+        t2 = h.submit_host(batches[2], outs[2], ns[2], K=K, dist=dist, marker_size=0.05)
+        h.wait(t1)
+        thr1 = h.thresholded(1, (1080, 1920))            # frame 1 of the batch of ticket t1 = frame 3 of the stream
+        h.wait(t2)
+        with pytest.raises(capi.ArucoHipError):          # a ticket is waited for once
+            h.wait(t2)
+        for b in range(3):
+            for f in range(2):
+                assert outs[b][f, :ns[b][f]].tobytes() == ref[b][f].tobytes()
+        assert sum(int(n.sum()) for n in ns) >= 100
+        h.set_pipeline_depth(0)
+        h.detect_batch_host(fr[2:4])
+        assert np.array_equal(h.thresholded(1, (1080, 1920)), thr1)
+    finally:
+        h.close()
