@@ -32,7 +32,7 @@ class Params(C.Structure):
     _fields_ = [("thres_method", C.c_int32), ("thres_param1_range", C.c_int32), ("thres_param1", C.c_double),
                 ("thres_param2", C.c_double), ("corner_method", C.c_int32), ("warp_size", C.c_int32),
                 ("min_size", C.c_float), ("max_size", C.c_float), ("border_dist", C.c_float),
-                ("use_locked_corners", C.c_int32), ("decoder_kind", C.c_int32), ("reserved_", C.c_int32)]
+                ("use_locked_corners", C.c_int32), ("decoder_kind", C.c_int32), ("erode", C.c_int32)]
 
 
 class Marker(C.Structure):
@@ -68,6 +68,7 @@ SYMBOLS = [
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
     "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray", "arucohip_set_dictionary",
     "arucohip_set_decoder_callback",
+    "arucohip_undistort", "arucohip_gl_modelview_n", "arucohip_gl_modelview_batch",
     "arucohip_set_pipeline_depth", "arucohip_detect_batch_submit", "arucohip_detect_batch_wait",
     "arucohip_mgpu_device_count", "arucohip_mgpu_create", "arucohip_mgpu_destroy", "arucohip_mgpu_size", "arucohip_mgpu_handle",
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
@@ -131,7 +132,10 @@ def load():
     L.arucohip_detect_batch_bgr.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i]
     L.arucohip_bgr_to_gray.argtypes = [vp, vp, i, i, sz, vp]
     L.arucohip_set_dictionary.argtypes = [vp, i, i, vp, i, f]
+    L.arucohip_undistort.argtypes = [vp, vp, i, i, i, sz, sz, i, i, vp, vp, i, vp, i]
     L.arucohip_gl_modelview.argtypes = [vp, vp, vp]
+    L.arucohip_gl_modelview_n.argtypes = [vp, i, vp]
+    L.arucohip_gl_modelview_batch.argtypes = [vp, i, i, vp, vp]
     L.arucohip_ogre_pose.argtypes = [vp, vp, vp, vp]
     L.arucohip_gl_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
     L.arucohip_ogre_projection.argtypes = [vp, i, i, i, i, C.c_double, C.c_double, i, vp]
@@ -267,6 +271,22 @@ class Handle:
         self._chk(self.L.arucohip_detect_batch_bgr(self.h, _ptr(fr), nf, w, h, 3 * w, 3 * w * h, 0, _ptr(Ka), _ptr(da),
                                                    0 if da is None else da.size, float(marker_size), int(bool(y_perp)), _ptr(out), cap, _ptr(n), 0))
         return [out[f, :n[f]].copy() for f in range(nf)]
+
+    def undistort(self, img, K, dist):
+        """cv::undistort of host frames: [H][W], [H][W][3], [N][H][W] (gray batch) -> same shape."""
+        a = np.ascontiguousarray(img, dtype=np.uint8)
+        if a.ndim == 2:
+            n, (hgt, wid), cn = 1, a.shape, 1
+        elif a.ndim == 3 and a.shape[2] == 3:
+            n, (hgt, wid), cn = 1, a.shape[:2], 3
+        else:
+            n, hgt, wid = a.shape
+            cn = 1
+        Ka, da = _f32(K), _f32(dist)
+        out = np.empty_like(a)
+        self._chk(self.L.arucohip_undistort(self.h, _ptr(a), n, wid, hgt, wid * cn, wid * hgt * cn, cn, 0, _ptr(Ka), _ptr(da),
+                                            0 if da is None else da.size, _ptr(out), 0))
+        return out
 
     def bgr_to_gray(self, bgr):
         b = np.ascontiguousarray(bgr, dtype=np.uint8)
@@ -437,6 +457,13 @@ class Handle:
         c = np.zeros(8, np.uint32)
         self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
         return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}
+
+    def gl_modelview_batch(self, nframes, cap=64):
+        """Marker::glGetModelViewMatrix for every marker of the last batch (device kernel): list per frame of [n][16]."""
+        mv = np.zeros((nframes, cap, 16), np.float64)
+        n = np.zeros(nframes, np.int32)
+        self._chk(self.L.arucohip_gl_modelview_batch(self.h, nframes, cap, _ptr(mv), _ptr(n)))
+        return [mv[f, :n[f]].copy() for f in range(nframes)]
 
     def board_detect_batch(self, nframes, ids, obj, info_type, K=None, dist=None, marker_size=-1.0, repj_err_thres=-1.0, y_perp=False):
         """BoardDetector::detect on the device-resident markers of the last detect_batch call, all frames at once."""

@@ -42,6 +42,16 @@ struct arucohip_handle {
     size_t gray_bytes = 0;
     uint8_t* d_bgr = nullptr;         // staging for host BGR frames
     size_t bgr_bytes = 0;
+    uint8_t* d_erode = nullptr;       // eroded planes (params.erode)
+    size_t erode_bytes = 0;
+    // frame undistortion (arucohip_undistort): the map of the last camera is kept
+    short2* d_umap_xy = nullptr;
+    uint16_t* d_umap_f = nullptr;
+    size_t umap_px = 0;
+    int umap_w = 0, umap_h = 0, umap_nd = -1;
+    float umap_K[9] = {}, umap_d[8] = {};
+    uint8_t* d_undist = nullptr;      // undistorted frames when the caller wants them on the host
+    size_t undist_bytes = 0;
     // highly reliable markers (arucohip_set_dictionary)
     uint64_t* d_hrm = nullptr;
     int hrm_n = 0, hrm_count = 0, hrm_tau0 = 0;
@@ -64,6 +74,8 @@ struct arucohip_handle {
     int* d_small_i = nullptr;
     uint8_t* d_patch = nullptr;       // MAX_WARP^2
     void* d_board = nullptr;          // batched board results + ids
+    double* d_gl = nullptr;           // batched GL modelview matrices
+    size_t gl_bytes = 0;
     // last call
     int last_w = 0, last_h = 0, last_frames = 0, last_nthr = 1;
     const uint8_t* last_gray = nullptr;
@@ -169,7 +181,9 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
     if (p->thres_method == ARUCOHIP_THRES_CANNY) return fail(h, ARUCOHIP_E_UNSUPPORTED, "CANNY threshold is not on the accelerated path");
     if (p->thres_method != ARUCOHIP_THRES_FIXED && p->thres_method != ARUCOHIP_THRES_ADPT) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
     if (p->corner_method < ARUCOHIP_CORNER_NONE || p->corner_method > ARUCOHIP_CORNER_LINES) return fail(h, ARUCOHIP_E_INVALID, "bad corner method");
-    if (p->use_locked_corners) return fail(h, ARUCOHIP_E_UNSUPPORTED, "locked corners are not on the accelerated path");
+    if (p->use_locked_corners && (p->corner_method == ARUCOHIP_CORNER_HARRIS || p->corner_method == ARUCOHIP_CORNER_SUBPIX) &&
+        ((int)p->thres_param1 < 1 || (int)p->thres_param1 > 31))
+        return fail(h, ARUCOHIP_E_UNSUPPORTED, "locked corners: window (thres_param1) outside 1..31");
     if (p->decoder_kind < ARUCOHIP_DECODER_FIDUCIAL_5X5 || p->decoder_kind > ARUCOHIP_DECODER_USER) return fail(h, ARUCOHIP_E_INVALID, "bad decoder kind");
     if (p->thres_param1_range < 0 || 2 * p->thres_param1_range + 1 > 16) return fail(h, ARUCOHIP_E_UNSUPPORTED, "threshold range too large");
     if (p->corner_method == ARUCOHIP_CORNER_SUBPIX && (int)p->thres_param1 > 15) return fail(h, ARUCOHIP_E_UNSUPPORTED, "SUBPIX window > 15");
@@ -194,7 +208,7 @@ static void free_all(arucohip_handle* h) {
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -473,6 +487,7 @@ static int make_detect_params(arucohip_handle* h, int W, int H, DetectParams* dp
     dp->bx0 = std::min(x1, x2), dp->by0 = std::min(y1, y2);
     dp->bx1 = std::max(x1, x2), dp->by1 = std::max(y1, y2);
     dp->subpix_win = (int)p.thres_param1;
+    dp->locked = p.use_locked_corners != 0, dp->locked_wsize = (int)p.thres_param1;   // findCornerMaxima(Corners, grey, _thresParam1)
     dp->decoder = p.decoder_kind;
     if (p.decoder_kind == ARUCOHIP_DECODER_HRM) {
         if (!h->d_hrm || h->hrm_count <= 0) return fail(h, ARUCOHIP_E_INVALID, "decoder HRM without a dictionary (arucohip_set_dictionary)");
@@ -602,6 +617,8 @@ static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, 
     launch_frame_candidates(h->stream, g, nframes, dp, h->buf);
 }
 
+static int grow(arucohip_handle* h, uint8_t** buf, size_t* have, size_t need);
+
 static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp, const CamModel& cam) {
     hipStream_t s = h->stream;
     Buffers& b = h->buf;
@@ -622,6 +639,11 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     MARK(0);
     if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));
     launch_threshold(s, gray_dev, g, nframes, dp, b);
+    if (h->params.erode) {
+        int rc_ = grow(h, &h->d_erode, &h->erode_bytes, (size_t)nframes * dp.nthr * g.width * g.height);
+        if (rc_) return rc_;
+        launch_erode(s, g, nframes * dp.nthr, b, h->d_erode);
+    }
     if (h->ev_thr) HIPCHK(h, hipEventRecord(h->ev_thr, s));
     MARK(1);
     if (b.seg_mode) {
@@ -659,8 +681,10 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     MARK(6);
     launch_refine_lines(s, g, nframes, dp, cam, b);
     MARK(7);
-    if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX)
+    if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX) {
+        if (dp.locked) launch_locked_corners(s, gray_dev, g, nframes, dp, b);   // markerdetector.cpp:398-399
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
+    }
     MARK(8);
     launch_finalize(s, g, nframes, dp, cam, b);
     MARK(9);
@@ -876,6 +900,58 @@ int arucohip_bgr_to_gray(arucohip_handle* h, const uint8_t* bgr, int W, int H, s
     if ((rc = stage_frames(h, bgr, 1, W, H, row_stride, (size_t)H * row_stride, 0, 3, &dev, &g))) return rc;
     HIPCHK(h, hipMemcpyAsync(gray, dev, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ARUCOHIP_OK;
+}
+
+// cv::undistort(src, dst, K, dist) as the reference's GL apps call it before detect()
+// (utils/aruco_test_gl.cpp:237-240, utils/aruco_test_board_gl.cpp:265-268)
+int arucohip_undistort(arucohip_handle* h, const uint8_t* src, int nframes, int W, int H, size_t row_stride, size_t frame_stride, int channels,
+                       int src_on_device, const float* K, const float* dist, int ndist, uint8_t* dst, int dst_on_device) {
+    if (!h || !src || !dst || !K || (channels != 1 && channels != 3) || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return ARUCOHIP_E_INVALID;
+    int rc = check_geometry(h, nframes, W, H, row_stride, channels);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // map of this camera: recomputed only when size, K or dist change
+    bool same = h->d_umap_xy && h->umap_w == W && h->umap_h == H && h->umap_nd == ndist && std::memcmp(h->umap_K, K, sizeof(h->umap_K)) == 0 &&
+                (ndist == 0 || std::memcmp(h->umap_d, dist, ndist * sizeof(float)) == 0);
+    if (!same) {
+        const size_t px = (size_t)W * H;
+        if (px > h->umap_px) {
+            if (h->d_umap_xy) HIPCHK(h, hipFree(h->d_umap_xy));
+            if (h->d_umap_f) HIPCHK(h, hipFree(h->d_umap_f));
+            h->d_umap_xy = nullptr, h->d_umap_f = nullptr, h->umap_px = 0;
+            HIPCHK(h, hipMalloc((void**)&h->d_umap_xy, px * sizeof(short2)));
+            HIPCHK(h, hipMalloc((void**)&h->d_umap_f, px * sizeof(uint16_t)));
+            h->umap_px = px;
+        }
+        launch_undist_map(s, W, H, K, dist, ndist, h->d_umap_xy, h->d_umap_f);
+        HIPCHK(h, hipGetLastError());
+        h->umap_w = W, h->umap_h = H, h->umap_nd = ndist;
+        std::memcpy(h->umap_K, K, sizeof(h->umap_K));
+        if (ndist) std::memcpy(h->umap_d, dist, ndist * sizeof(float));
+    }
+    const size_t fbytes = (size_t)W * H * channels;
+    const uint8_t* sdev = src;
+    size_t rs = row_stride, fs = frame_stride;
+    if (!src_on_device) {
+        if ((rc = grow(h, &h->d_bgr, &h->bgr_bytes, (size_t)nframes * fbytes))) return rc;
+        for (int f = 0; f < nframes; f++)
+            HIPCHK(h, hipMemcpy2DAsync(h->d_bgr + (size_t)f * fbytes, (size_t)W * channels, src + (size_t)f * frame_stride, row_stride, (size_t)W * channels, H,
+                                       hipMemcpyHostToDevice, s));
+        sdev = h->d_bgr, rs = (size_t)W * channels, fs = fbytes;
+    }
+    uint8_t* ddev = dst;
+    if (!dst_on_device) {
+        if ((rc = grow(h, &h->d_undist, &h->undist_bytes, (size_t)nframes * fbytes))) return rc;
+        ddev = h->d_undist;
+    }
+    launch_remap(s, sdev, rs, fs, W, H, channels, nframes, h->d_umap_xy, h->d_umap_f, ddev);
+    HIPCHK(h, hipGetLastError());
+    if (!dst_on_device) {
+        HIPCHK(h, hipMemcpyAsync(dst, ddev, (size_t)nframes * fbytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
     return ARUCOHIP_OK;
 }
 
@@ -1222,6 +1298,29 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
         HIPCHK(h, hipMemcpy(w->h_counters, w->buf.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (w->h_counters[CNT_STATUS] & ST_MARKER_OVERFLOW) return fail(h, ARUCOHIP_E_CAPACITY, "a frame has more than 128 board markers");
     }
+    return ARUCOHIP_OK;
+}
+
+// SURVEY §8 row f4, batched: Marker::glGetModelViewMatrix (src/marker.h:90) for every marker of the last batch in one launch
+int arucohip_gl_modelview_batch(arucohip_handle* h, int nframes, int cap, double* modelview, int32_t* n_out) {
+    if (!h || !modelview || !n_out || cap < 1) return ARUCOHIP_E_INVALID;
+    h = active(h);
+    if (h->last_chunks > 1) return fail(h, ARUCOHIP_E_UNSUPPORTED, "not available for batches split over chunk streams");
+    if (nframes < 1 || nframes > h->last_frames) return fail(h, ARUCOHIP_E_INVALID, "nframes exceeds the last batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t need = (size_t)nframes * cap * 16 * sizeof(double);
+    if (need > h->gl_bytes) {
+        if (h->d_gl) HIPCHK(h, hipFree(h->d_gl));
+        h->d_gl = nullptr, h->gl_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_gl, need));
+        h->gl_bytes = need;
+    }
+    launch_gl_modelview(h->stream, nframes, cap, h->buf, h->d_gl);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(modelview, h->d_gl, need, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(n_out, h->buf.nmarkers, (size_t)nframes * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int f = 0; f < nframes; f++) n_out[f] = std::min(std::min(n_out[f], cap), h->buf.cap_markers);
     return ARUCOHIP_OK;
 }
 

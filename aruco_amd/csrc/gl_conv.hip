@@ -46,6 +46,15 @@ int arucohip_gl_modelview(const double* rvec, const double* tvec, double* m) {
     return ARUCOHIP_OK;
 }
 
+int arucohip_gl_modelview_n(const arucohip_marker_t* markers, int n, double* modelview) {
+    if (n < 0 || (n > 0 && (!markers || !modelview))) return ARUCOHIP_E_INVALID;
+    for (int i = 0; i < n; i++) {
+        if (!markers[i].has_pose) return ARUCOHIP_E_INVALID;   // "extrinsic parameters are not set" (utils.cpp:34-36)
+        arucohip_gl_modelview(markers[i].rvec, markers[i].tvec, modelview + (size_t)i * 16);
+    }
+    return ARUCOHIP_OK;
+}
+
 int arucohip_ogre_pose(const double* rvec, const double* tvec, double* position, double* orientation) {
     if (!rvec || !tvec || !position || !orientation) return ARUCOHIP_E_INVALID;
     position[0] = -tvec[0], position[1] = -tvec[1], position[2] = +tvec[2];

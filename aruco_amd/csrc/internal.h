@@ -96,6 +96,7 @@ struct DetectParams {
     int min_contour, max_contour;   // contour length bounds (exclusive)
     int bx0, by0, bx1, by1;         // valid region of the border filter [bx0,bx1) x [by0,by1)
     int subpix_win;
+    int locked, locked_wsize;       // _useLockedCorners and the window of findCornerMaxima (int(_thresParam1))
     // decoder: 0 = 5x5 fiducial, 1 = highly reliable markers with the handle's dictionary, 2 = host callback (the device
     // only warps; ids come back through launch_set_decoded)
     int decoder;
@@ -141,9 +142,19 @@ struct Buffers {
     int cap_quads, cap_cands, cap_markers;   // per frame
 };
 
+// Every kernel after the threshold pass is a chain of dependent steps on few wavefronts. With batches in flight its waves
+// share SIMDs with the next batch's streaming threshold waves, which are always ready to issue; at equal priority the
+// dependent chain only gets every n-th issue slot. Raised priority lets the sparse chains issue whenever they can — they leave
+// most slots to the streaming waves anyway.
+__device__ __forceinline__ void latency_bound_priority() { __builtin_amdgcn_s_setprio(3); }
+
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_bgr2gray(hipStream_t s, const uint8_t* bgr, size_t row_stride, size_t frame_stride, int width, int height, int nframes, uint8_t* gray);
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+void launch_undist_map(hipStream_t s, int W, int H, const float* K, const float* dist, int ndist, short2* xy, uint16_t* fxy);
+void launch_remap(hipStream_t s, const uint8_t* src, size_t row_stride, size_t frame_stride, int W, int H, int cn, int nframes, const short2* xy,
+                  const uint16_t* fxy, uint8_t* dst);
+void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 struct WalkFork {
@@ -159,12 +170,14 @@ void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, con
 void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_set_decoded(hipStream_t s, const Buffers& b, uint32_t n, const int2* id_nrot_dev);
 void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
+void launch_locked_corners(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
 void launch_pose(hipStream_t s, int nframes, const CamModel& cam, const Buffers& b);
 void launch_warp_only(hipStream_t s, const uint8_t* gray, const FrameGeom& g, const float* quad_dev, int size, uint8_t* dst_dev);
 void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out);
 void launch_project_points(hipStream_t s, const float* obj, int npts, const double* rt, const CamModel& cam, float* img_out);
+void launch_gl_modelview(hipStream_t s, int nframes, int cap, const Buffers& b, double* out_dev);
 void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const CamModel& cam);
 void launch_board_pose(hipStream_t s, int nframes, const Buffers& b, const int32_t* ids, const float* obj, int nboard, int info_type,
                        float marker_size, float repj_thres, const CamModel& cam, arucohip_board_t* out, float* prob);

@@ -80,6 +80,7 @@ constexpr int CAND_THREADS = 256;
 constexpr int CAND_STAGE = 512;   // staged records per list and round
 
 __global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
+    latency_bound_priority();
     __shared__ uint2 s_keep[2][CAND_STAGE];
     __shared__ uint2 s_long[CAND_STAGE];
     __shared__ uint32_t s_n[2], s_base[2], s_nlong;
@@ -487,6 +488,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
 }
 
 __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
+    latency_bound_priority();
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int chunk = rest % WALK_BLOCKS, plane = (rest / WALK_BLOCKS) * 8 + xcd;
     if (plane >= a.nplanes) return;
@@ -541,6 +543,7 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
 }
 
 __global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
+    latency_bound_priority();
     __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
     if ((int)blockIdx.x < a.gen_blocks)
         walk_generation<false>(a, blockIdx.x, rows);
@@ -877,6 +880,7 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
 }
 
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
+    latency_bound_priority();
     __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
@@ -934,6 +938,7 @@ __device__ __forceinline__ float quad_perimeter_i(const int16_t* x, const int16_
 }
 
 __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
+    latency_bound_priority();
     __shared__ int16_t sx[MAXQ][4], sy[MAXQ][4];
     __shared__ int s_cdesc[MAXQ];
     __shared__ uint8_t s_swapped[MAXQ], s_rem[MAXQ];

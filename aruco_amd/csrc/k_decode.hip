@@ -130,6 +130,7 @@ struct LaneMat {
 };
 
 __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
+    latency_bound_priority();
     __shared__ double sA[64 * 64], sb[8 * 64];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
@@ -222,6 +223,7 @@ constexpr int HCOPIES = 32, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+
 constexpr int HWCOPIES = 8, HWPITCH = 257;
 static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
+    latency_bound_priority();
     __shared__ uint32_t hist[HCOPIES * HPITCH];
     __shared__ double siM[9];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
 // halfwords); the two 256-step sweeps then never wait for HBM.
 constexpr int OTSU_PITCH = 66;   // halfwords per bin row: 64 candidates + padding against bank conflicts
 __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
+    latency_bound_priority();
     __shared__ uint16_t sh[256 * OTSU_PITCH];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const uint32_t base = blockIdx.x * 64;
@@ -376,6 +379,7 @@ __device__ __forceinline__ int hamm_rows(const uint32_t v[5]) {
 }
 
 __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
+    latency_bound_priority();
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x;
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
@@ -456,6 +460,7 @@ struct HrmArgs {
 };
 
 __global__ __launch_bounds__(64) void hrm_decode_kernel(DecodeArgs a, HrmArgs d) {
+    latency_bound_priority();
     const uint32_t ncand = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x, n = d.n, nn = n * n;
     for (uint32_t idx = blockIdx.x; idx < ncand; idx += gridDim.x) {

@@ -32,6 +32,7 @@ struct FinalArgs {
 };
 
 __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
+    latency_bound_priority();
     __shared__ int s_src[MAXM];      // candidate index, sorted by (id, candidate order)
     __shared__ int s_id[MAXM];
     __shared__ uint8_t s_rem[MAXM];
@@ -117,6 +118,7 @@ __device__ inline void marker_pose(arucohip_marker_t* m, const CamModel& cam) {
 }
 
 __global__ __launch_bounds__(64) void pose_kernel(arucohip_marker_t* markers, const int32_t* nmarkers, int cap_markers, int nframes, CamModel cam) {
+    latency_bound_priority();
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int frame = gid / cap_markers, i = gid - frame * cap_markers;
     if (frame >= nframes || i >= min(nmarkers[frame], cap_markers)) return;
@@ -187,6 +189,7 @@ struct BoardArgs {
 };
 
 __global__ __launch_bounds__(64) void board_pose_kernel(BoardArgs a) {
+    latency_bound_priority();
     __shared__ float s_obj[MAX_BOARD_POINTS * 3], s_img[MAX_BOARD_POINTS * 2], s_obj2[MAX_BOARD_POINTS * 3], s_img2[MAX_BOARD_POINTS * 2];
     __shared__ int s_npts, s_nmark, s_n2;
     const int frame = blockIdx.x, lane = threadIdx.x;
@@ -270,6 +273,34 @@ void launch_board_pose(hipStream_t s, int nframes, const Buffers& b, const int32
     a.ids = ids, a.obj = obj, a.nboard = nboard, a.info_type = info_type, a.marker_size = marker_size, a.repj_thres = repj_thres;
     a.cam = cam, a.out = out, a.prob = prob, a.counters = b.counters;
     hipLaunchKernelGGL(board_pose_kernel, dim3(nframes), dim3(64), 0, s, a);
+}
+
+// GetGLModelViewMatrix (src/utils.cpp:32-69) for every marker of the batch, one lane per marker slot: column-major 4x4
+// from the marker's rvec / tvec (third row negated: OpenGL looks down -z); markers without a pose give a zero matrix.
+__global__ void gl_modelview_kernel(const arucohip_marker_t* markers, const int32_t* nmarkers, int cap_markers, int nframes, int cap, double* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = gid / cap, i = gid - frame * cap;
+    if (frame >= nframes) return;
+    double* m = out + (size_t)gid * 16;
+    const bool live = i < min(nmarkers[frame], cap_markers) && markers[(size_t)frame * cap_markers + i].has_pose;
+    if (!live) {
+        for (int k = 0; k < 16; k++) m[k] = 0.0;
+        return;
+    }
+    const arucohip_marker_t& mk = markers[(size_t)frame * cap_markers + i];
+    double R[9];
+    rodrigues_vec2mat(mk.rvec, R, nullptr);
+    for (int col = 0; col < 3; col++) {
+        m[0 + col * 4] = R[0 * 3 + col];
+        m[1 + col * 4] = R[1 * 3 + col];
+        m[2 + col * 4] = -R[2 * 3 + col];
+        m[3 + col * 4] = 0.0;
+    }
+    m[12] = mk.tvec[0], m[13] = mk.tvec[1], m[14] = -mk.tvec[2], m[15] = 1.0;
+}
+void launch_gl_modelview(hipStream_t s, int nframes, int cap, const Buffers& b, double* out_dev) {
+    const int total = nframes * cap;
+    hipLaunchKernelGGL(gl_modelview_kernel, dim3((total + 255) / 256), dim3(256), 0, s, b.markers, b.nmarkers, b.cap_markers, nframes, cap, out_dev);
 }
 
 // rotateXAxis on a pose stored as rt[0..2]

@@ -204,6 +204,7 @@ __device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int l
 // one wave per decoded candidate, taken from the flat candidate list of the batch (a grid over every candidate slot of
 // every frame would be 90 % empty workgroups)
 __global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
+    latency_bound_priority();
     const int lane = threadIdx.x;
     const uint32_t nlist = min(a.counters[CNT_NCAND], a.cap_flat);
     for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) refine_one(a, a.cand_list[li], lane);
@@ -234,6 +235,7 @@ struct PixArgs {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 __global__ __launch_bounds__(64) void refine_pixels_kernel(PixArgs a) {
+    latency_bound_priority();
     __shared__ float buf[33 * 33];
     __shared__ uint8_t loc[17 * 17];
     const int frame = blockIdx.z, ci = blockIdx.y, corner = blockIdx.x, lane = threadIdx.x;
@@ -338,6 +340,134 @@ __global__ __launch_bounds__(64) void refine_pixels_kernel(PixArgs a) {
         }
     }
     if (lane == 0) cand->c[2 * corner] = rx, cand->c[2 * corner + 1] = ry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Locked-corner pre-pass: findCornerMaxima (/root/reference/src/markerdetector.cpp:157-199, enabled by :291-295, called
+// at :398-399 before HARRIS / SUBPIX). One wavefront per corner of a decoded candidate: cv::cornerHarris(block 3, aperture 3,
+// k 0.04) on the window of +-wsize pixels around the corner (the derivatives at the window's rim read the image around
+// it; REFLECT_101 at the image border), cv::integral in double, every interior response replaced by the sum of the 4x4
+// block that starts at it, then the arg max of the response weighted by 1 - (L1 distance to the window centre) / (half
+// width + half height): first maximum in raster order, strictly positive, else (-1, -1) + window origin like the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int LOCK_MAXW = 62;   // window side: 2 * wsize, wsize <= 31
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+struct LockArgs {
+    const uint8_t* gray;
+    size_t row_stride, frame_stride;
+    int width, height;
+    Cand* cands;
+    const int32_t* ncands;
+    int cap_cands, wsize;
+};
+
+__global__ __launch_bounds__(64) void locked_corners_kernel(LockArgs a) {
+    latency_bound_priority();
+    // 61.5 KB: the response, then either the three derivative products or (once they are summed) the integral image
+    constexpr int N = LOCK_MAXW * LOCK_MAXW;
+    static_assert((LOCK_MAXW + 1) * (LOCK_MAXW + 1) * sizeof(double) <= 3 * N * sizeof(float), "the integral reuses the product arrays");
+    __shared__ float harr[N];
+    __shared__ __align__(8) float prod[3 * N];
+    float *sxx = prod, *sxy = prod + N, *syy = prod + 2 * N;
+    double* I = reinterpret_cast<double*>(prod);
+    const int frame = blockIdx.z, ci = blockIdx.y, corner = blockIdx.x, lane = threadIdx.x;
+    if (ci >= a.ncands[frame]) return;
+    Cand* cand = a.cands + (size_t)frame * a.cap_cands + ci;
+    if (cand->id < 0) return;
+    const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
+    const int W = a.width, H = a.height;
+    const size_t st = a.row_stride;
+    const float cx0 = cand->c[2 * corner], cy0 = cand->c[2 * corner + 1];
+    const int x0 = max(0, (int)(cx0 - (float)a.wsize)), y0 = max(0, (int)(cy0 - (float)a.wsize));
+    const int x1 = min(W, (int)(cx0 + (float)a.wsize)), y1 = min(H, (int)(cy0 + (float)a.wsize));
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (rw <= 0 || rh <= 0 || rw > LOCK_MAXW || rh > LOCK_MAXW) {
+        if (lane == 0) cand->c[2 * corner] = -1.f + (float)x0, cand->c[2 * corner + 1] = -1.f + (float)y0;
+        return;
+    }
+    const float scale = (float)(1. / ((double)(1 << 2) * 3 * 255.));
+    auto G = [&](int x, int y) -> float { return (float)src[(size_t)reflect101(y, H) * st + reflect101(x, W)]; };
+    for (int i = lane; i < rw * rh; i += WAVE) {
+        const int y = i / rw, x = i - y * rw, gx = x0 + x, gy = y0 + y;
+        const float dxm = G(gx + 1, gy - 1) - G(gx - 1, gy - 1), dxc = G(gx + 1, gy) - G(gx - 1, gy), dxp = G(gx + 1, gy + 1) - G(gx - 1, gy + 1);
+        const float dx = (dxm + dxp) * scale + dxc * (2.f * scale);
+        const float sm = (G(gx - 1, gy - 1) + G(gx + 1, gy - 1)) * scale + G(gx, gy - 1) * (2.f * scale);
+        const float sp = (G(gx - 1, gy + 1) + G(gx + 1, gy + 1)) * scale + G(gx, gy + 1) * (2.f * scale);
+        const float dy = sp - sm;
+        sxx[i] = dx * dx, sxy[i] = dx * dy, syy[i] = dy * dy;
+    }
+    __syncthreads();
+    for (int i = lane; i < rw * rh; i += WAVE) {
+        const int y = i / rw, x = i - y * rw;
+        float A = 0.f, B = 0.f, C = 0.f;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = reflect101(y + dy, rh);
+            float ra = 0.f, rb = 0.f, rc = 0.f;
+            for (int dx = -1; dx <= 1; dx++) {
+                const int q = yy * rw + reflect101(x + dx, rw);
+                ra += sxx[q], rb += sxy[q], rc += syy[q];
+            }
+            A += ra, B += rb, C += rc;
+        }
+        harr[i] = (float)((double)A * C - (double)B * B - 0.04 * ((double)A + C) * ((double)A + C));
+    }
+    __syncthreads();
+    // cv::integral in double with the reference's addition order: running sum along each row, then down the columns
+    const int iw = rw + 1;
+    for (int i = lane; i < iw * (rh + 1); i += WAVE) I[i] = 0.0;
+    __syncthreads();
+    for (int y = lane; y < rh; y += WAVE) {          // lane = row: I[y+1][x+1] temporarily holds the row's running sum
+        double row = 0;
+        for (int x = 0; x < rw; x++) {
+            row += (double)harr[y * rw + x];
+            I[(y + 1) * iw + x + 1] = row;
+        }
+    }
+    __syncthreads();
+    for (int x = lane; x < rw; x += WAVE)            // lane = column: I[y+1][x+1] = I[y][x+1] + row sum
+        for (int y = 0; y < rh; y++) I[(y + 1) * iw + x + 1] = I[y * iw + x + 1] + I[(y + 1) * iw + x + 1];
+    __syncthreads();
+    const int bls = 4;
+    for (int i = lane; i < rw * rh; i += WAVE) {
+        const int y = i / rw, x = i - y * rw;
+        if (y >= bls && y < rh - bls && x >= bls && x < rw - bls)
+            harr[i] = (float)(I[(y + bls) * iw + x + bls] - I[(y + bls) * iw + x] - I[y * iw + x + bls] + I[y * iw + x]);
+    }
+    __syncthreads();
+    const float ccx = (float)(rw / 2), ccy = (float)(rh / 2), den = (float)(rw / 2 + rh / 2);
+    double best = 0;
+    int besti = 0x7FFFFFFF;
+    for (int i = lane; i < rw * rh; i += WAVE) {
+        const int y = i / rw, x = i - y * rw;
+        const float d = (float)(fabsf(ccx - (float)x) + fabsf(ccy - (float)y)) / den;
+        const float wgt = (float)(1. - (double)d);
+        const double v = (double)(wgt * harr[i]);
+        if (v > best) best = v, besti = i;          // ascending i per lane: the lane's first maximum
+    }
+    // wave: largest value, lowest raster index among equals (the sequential scan keeps the first)
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) best = ob, besti = oi;
+    }
+    if (lane == 0) {
+        float bx = -1.f, by = -1.f;
+        if (best > 0 && besti != 0x7FFFFFFF) by = (float)(besti / rw), bx = (float)(besti - (besti / rw) * rw);
+        cand->c[2 * corner] = bx + (float)x0, cand->c[2 * corner + 1] = by + (float)y0;
+    }
+}
+
+void launch_locked_corners(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+    LockArgs a;
+    a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride, a.width = g.width, a.height = g.height;
+    a.cands = b.cands, a.ncands = b.ncands, a.cap_cands = b.cap_cands, a.wsize = p.locked_wsize;
+    hipLaunchKernelGGL(locked_corners_kernel, dim3(4, b.cap_cands, nframes), dim3(64), 0, s, a);
 }
 
 void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {

@@ -301,6 +301,36 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
     }
 }
 
+// Optional erosion (north_star; off by default, no reference counterpart in this snapshot): 3x3 minimum of the thresholded
+// image, pixels outside the image do not erode (cv::erode's default border). One thread per 4 pixels of a row.
+__global__ __launch_bounds__(256) void erode3x3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= W) return;
+    const size_t plane = (size_t)blockIdx.z * W * H;
+    const uint8_t* s = src + plane;
+    for (int j = 0; j < 4 && x0 + j < W; j++) {
+        const int x = x0 + j;
+        int v = 255;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = x + dx, yy = y + dy;
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) v = min(v, (int)s[(size_t)yy * W + xx]);
+            }
+        dst[plane + (size_t)y * W + x] = (uint8_t)v;
+    }
+}
+
+// thres planes -> eroded planes in `tmp`, tiles rebuilt from them, eroded planes copied back (the thresholded image the API
+// hands out is the eroded one)
+void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp) {
+    const int W = g.width, H = g.height;
+    hipLaunchKernelGGL(erode3x3_kernel, dim3((W / 4 + 256) / 256, H, nplanes), dim3(256), 0, s, b.thres, tmp, W, H);
+    FrameGeom tg = g;
+    tg.row_stride = (size_t)W, tg.frame_stride = (size_t)W * H;
+    launch_binary_planes(s, tmp, tg, nplanes, b);
+    (void)hipMemcpyAsync(b.thres, tmp, (size_t)nplanes * W * H, hipMemcpyDeviceToDevice, s);
+}
+
 // detectRectangles on a caller-supplied thresholded image (markerdetector.h:261): only the tiled binary image.
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b) {
     dim3 grid((g.width + STRIP - 1) / STRIP, (g.height + SEG - 1) / SEG, nframes);

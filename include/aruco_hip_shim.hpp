@@ -281,14 +281,35 @@ struct SharedHandle_ {
         static SharedHandle_* s = new SharedHandle_();
         return *s;
     }
-    arucohip_handle* ensure() {   // call with mu held
-        if (!h) {
+    int w = 0, hh = 0;
+    arucohip_handle* ensure(int width = 64, int height = 64) {   // call with mu held
+        if (!h || width > w || height > hh) {
+            arucohip_destroy(h);
+            h = nullptr;
+            w = std::max(w, width), hh = std::max(hh, height);
             const char* e = std::getenv("ARUCOHIP_DEVICE");
-            arucohip_throw_(arucohip_create(nullptr, e ? std::atoi(e) : 0, 64, 64, 1, &h), "arucohip_create", nullptr);
+            arucohip_throw_(arucohip_create(nullptr, e ? std::atoi(e) : 0, w, hh, 1, &h), "arucohip_create", nullptr);
         }
         return h;
     }
 };
+
+// cv::undistort(src, dst, cameraMatrix, distCoeffs) on the device: what the reference's GL apps run on
+// every frame before detect() (utils/aruco_test_gl.cpp:237-240). 8-bit frames, 1 or 3 channels.
+inline void undistort(const cv::Mat& src, cv::Mat& dst, const cv::Mat& cameraMatrix, const cv::Mat& distCoeffs) {
+    if (src.type() != CV_8UC1 && src.type() != CV_8UC3) arucohip_throw_(ARUCOHIP_E_INVALID, "undistort: CV_8UC1 or CV_8UC3 frames", nullptr);
+    float K[9], d[8];
+    if (!mat_to_K_(cameraMatrix, K)) arucohip_throw_(ARUCOHIP_E_INVALID, "undistort: camera matrix is empty", nullptr);
+    const int nd = mat_to_dist_(distCoeffs, d);
+    const int cn = src.type() == CV_8UC3 ? 3 : 1;
+    cv::Mat out(src.rows, src.cols, src.type());
+    SharedHandle_& sh = SharedHandle_::get();
+    std::lock_guard<std::mutex> lock(sh.mu);
+    arucohip_handle* h = sh.ensure(src.cols, src.rows);
+    arucohip_throw_(arucohip_undistort(h, src.data, 1, src.cols, src.rows, src.step, (size_t)src.rows * src.step, cn, 0, K, nd ? d : nullptr, nd, out.data, 0),
+                    "undistort", h);
+    dst = out;
+}
 
 class Marker : public std::vector<cv::Point2f> {
 public:
@@ -875,3 +896,10 @@ private:
 };
 
 }  // namespace aruco
+
+#if !ARUCOHIP_HAVE_OPENCV
+namespace cv {
+// the reference's apps spell it cv::undistort; without OpenCV the name resolves to the device implementation
+inline void undistort(const Mat& src, Mat& dst, const Mat& cameraMatrix, const Mat& distCoeffs) { aruco::undistort(src, dst, cameraMatrix, distCoeffs); }
+}  // namespace cv
+#endif

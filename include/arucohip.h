@@ -54,10 +54,13 @@ typedef struct arucohip_params {
     float min_size;             /* _minSize            default 0.04 */
     float max_size;             /* _maxSize            default 0.5  */
     float border_dist;          /* _borderDistThres    default 0.025 */
-    int32_t use_locked_corners; /* _useLockedCorners   default 0 (1 -> ARUCOHIP_E_UNSUPPORTED) */
+    int32_t use_locked_corners; /* _useLockedCorners   default 0; with HARRIS / SUBPIX: findCornerMaxima before the refinement */
     int32_t decoder_kind;       /* markerIdDetectorFunc: ARUCOHIP_DECODER_FIDUCIAL_5X5, ARUCOHIP_DECODER_HRM after
                                    arucohip_set_dictionary, ARUCOHIP_DECODER_USER after arucohip_set_decoder_callback */
-    int32_t reserved_;
+    int32_t erode;              /* north_star's "optional erosion": != 0 erodes the thresholded image with a 3x3 structuring
+                                   element (cv::erode(thres, thres, Mat()) semantics, outside pixels do not erode) before the
+                                   contour stage. Default 0: this snapshot of the reference dropped its enableErosion() as a
+                                   no-op (PortingManual.md:5-7), so there is no reference result to match */
 } arucohip_params_t;
 
 /* aruco::Marker (marker.h:46-53): id, 4 corners (x0,y0,..), ssize, Rvec/Tvec as double. 96 bytes. */
@@ -170,6 +173,15 @@ int arucohip_detect_batch_bgr(arucohip_handle* h, const uint8_t* frames, int nfr
                               int out_on_device);
 /* The conversion alone: one host BGR frame -> host gray frame (width*height bytes). */
 int arucohip_bgr_to_gray(arucohip_handle* h, const uint8_t* bgr, int width, int height, size_t row_stride, uint8_t* gray);
+/* SURVEY §8 row f3 — lens undistortion of the frames on the device: cv::undistort(src, dst, CameraMatrix, Distorsion), which
+ * the reference's GL apps run on every frame before detect() (utils/aruco_test_gl.cpp:237-240, utils/aruco_test_board_gl.cpp:
+ * 265-268; detect is then called with an empty distortion vector). 8-bit frames with `channels` = 1 or 3 interleaved channels;
+ * dst is tightly packed (nframes x height x width x channels), in host or device memory; with dst_on_device the call is
+ * asynchronous on the handle's stream, so arucohip_detect_batch(frames_on_device = 1) can follow without a round trip. The
+ * fixed-point map (OpenCV's CV_16SC2 form: bilinear, 5 fractional bits, constant 0 outside) is computed once per (size, K, dist)
+ * and kept in the handle. */
+int arucohip_undistort(arucohip_handle* h, const uint8_t* src, int nframes, int width, int height, size_t row_stride, size_t frame_stride,
+                       int channels, int src_on_device, const float* K, const float* dist, int ndist, uint8_t* dst, int dst_on_device);
 /* After an asynchronous batch: synchronise and report device-side overflow / capacity conditions. */
 int arucohip_batch_status(arucohip_handle* h);
 /* With the environment variable ARUCOHIP_STREAMS = 2..8 a large batch is processed as that many chunks of consecutive
@@ -284,6 +296,11 @@ int arucohip_mgpu_detect_streams(arucohip_mgpu* m, const uint8_t* const* frames_
  * GetGLModelViewMatrix (src/utils.cpp:32-69; Marker::glGetModelViewMatrix src/marker.h:90, Board:: src/board.h:109):
  * column-major 4x4 from rvec / tvec (3 doubles each). */
 int arucohip_gl_modelview(const double* rvec, const double* tvec, double* modelview16);
+/* The same for n markers that carry a pose (has_pose), modelview16: n*16 doubles. */
+int arucohip_gl_modelview_n(const arucohip_marker_t* markers, int n, double* modelview16);
+/* ... and for every marker of the LAST batch on the device (one launch, a lane per marker): modelview = host array of
+ * nframes*cap*16 doubles (frame-major, zero matrices for slots without a posed marker), n_out[f] = markers of frame f. */
+int arucohip_gl_modelview_batch(arucohip_handle* h, int nframes, int cap, double* modelview, int32_t* n_out);
 /* GetOgrePoseParameters (src/utils.cpp:71-147): position[3], orientation[4] = quaternion (w, x, y, z). */
 int arucohip_ogre_pose(const double* rvec, const double* tvec, double* position3, double* orientation4);
 /* CameraParameters::glGetProjectionMatrix (src/cameraparameters.cpp:226-266) including the CameraParameters::resize

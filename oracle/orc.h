@@ -10,6 +10,7 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code, and only as
 // the checker / baseline. The product path (aruco_amd/csrc, include/arucohip.h) never links or calls it.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -35,7 +36,7 @@ struct Params {
     float min_size = 0.04f, max_size = 0.5f;
     int warp_size = 56;
     float border_dist = 0.025f;
-    int use_locked_corners = 0; // unsupported
+    int use_locked_corners = 0; // findCornerMaxima before HARRIS / SUBPIX
     // OpenCV-version knobs (see DESIGN.md "oracle pinning")
     int approx_inner_product = 1;  // approxPolyDP clean-up also requires successive inner product >= 0
 };
@@ -125,6 +126,10 @@ int hrm_detect(uint8_t* patch, int size, const HrmDict& d, int* nrot);
 void refine_lines(Candidate& cand, const float* K, const float* dist, int ndist);
 void corner_subpix(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n, int win, int max_iter, double eps);
 void corner_harris_refine(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n);
+// orc_extra.cpp
+void undistort_8u(const uint8_t* src, int w, int h, size_t stride, int cn, const float K[9], const float* dist, int ndist, uint8_t* dst);
+void find_corner_maxima(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n, int wsize);
+void corner_harris_window(const uint8_t* gray, int w, int h, int stride, int x0, int y0, int x1, int y1, std::vector<float>& harr);
 float board_detect(const std::vector<Marker>& detected, const BoardConf& bc, const float* K, const float* dist,
                    int ndist, float marker_size, float repj_err_thres, int y_perp, Board& out);
 

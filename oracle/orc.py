@@ -255,6 +255,34 @@ def corner_harris(gray, pts):
     return p
 
 
+def undistort(img, K, dist):
+    """cv::undistort(img, out, K, dist) for an 8-bit image [H][W] or [H][W][3]."""
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    Ka, da = _f32(K)[0], _f32(dist)[0]
+    out = np.empty_like(a)
+    lib().orc_undistort(a.ctypes.data_as(C.c_void_p), w, h, w * cn, cn, Ka.ctypes.data_as(C.c_void_p),
+                        None if da is None else da.ctypes.data_as(C.c_void_p), 0 if da is None else da.size, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def find_corner_maxima(gray, pts, wsize):
+    g, gp = _u8(gray)
+    h, w = g.shape
+    p = np.ascontiguousarray(pts, dtype=np.float32).copy()
+    lib().orc_find_corner_maxima(gp, w, h, w, p.ctypes.data_as(C.c_void_p), len(p.reshape(-1, 2)), int(wsize))
+    return p
+
+
+def corner_harris_window(gray, x0, y0, x1, y1):
+    g, gp = _u8(gray)
+    h, w = g.shape
+    out = np.zeros((y1 - y0, x1 - x0), np.float32)
+    lib().orc_corner_harris_window(gp, w, h, w, x0, y0, x1, y1, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def board_detect(markers, ids, obj, info_type, K, dist, marker_size, repj_thres=-1.0, y_perp=False):
     n = len(markers)
     ms = (OrcMarker * max(n, 1))()

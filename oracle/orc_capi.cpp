@@ -178,6 +178,18 @@ void orc_corner_subpix(const uint8_t* gray, int w, int h, int stride, float* xy,
 void orc_corner_harris(const uint8_t* gray, int w, int h, int stride, float* xy, int n) {
     corner_harris_refine(gray, w, h, stride, (Pt2f*)xy, n);
 }
+void orc_undistort(const uint8_t* src, int w, int h, int stride, int cn, const float* K, const float* dist, int ndist, uint8_t* dst) {
+    undistort_8u(src, w, h, (size_t)stride, cn, K, dist, ndist, dst);
+}
+void orc_find_corner_maxima(const uint8_t* gray, int w, int h, int stride, float* xy, int n, int wsize) {
+    find_corner_maxima(gray, w, h, stride, (Pt2f*)xy, n, wsize);
+}
+int orc_corner_harris_window(const uint8_t* gray, int w, int h, int stride, int x0, int y0, int x1, int y1, float* out) {
+    std::vector<float> v;
+    corner_harris_window(gray, w, h, stride, x0, y0, x1, y1, v);
+    std::memcpy(out, v.data(), v.size() * sizeof(float));
+    return (int)v.size();
+}
 float orc_board_detect(const orc_marker_t* ms, int n, const int32_t* ids, const float* obj, int nboard, int info_type,
                        const float* K, const float* dist, int ndist, float marker_size, float repj_thres, int y_perp,
                        orc_marker_t* out_ms, int* n_out, double* rvec, double* tvec, int* has_pose) {

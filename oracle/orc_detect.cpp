@@ -398,7 +398,7 @@ int Detector::detect(const uint8_t* gray, int W, int H, int stride, const float*
                      float marker_size, int y_perp, std::vector<Marker>& out) {
     out.clear();
     w = W, h = H;
-    if (prm.thres_method == 2 || prm.use_locked_corners) return -2;  // CANNY / locked corners: not restated
+    if (prm.thres_method == 2) return -2;  // CANNY: not restated
     // thresholds :322-334
     const int nthr = 2 * prm.thres_range + 1;
     std::vector<std::vector<uint8_t>> thr(nthr, std::vector<uint8_t>((size_t)W * H));
@@ -451,6 +451,8 @@ int Detector::detect(const uint8_t* gray, int W, int H, int stride, const float*
         std::vector<Pt2f> cs;
         for (auto& m : det)
             for (int k = 0; k < 4; k++) cs.push_back(m.c[k]);
+        // locked corners (:398-399): search the corner in the surroundings of the estimated location first
+        if (prm.use_locked_corners) find_corner_maxima(gray, W, H, stride, cs.data(), (int)cs.size(), (int)prm.thres_p1);
         if (prm.corner_method == 1)
             corner_harris_refine(gray, W, H, stride, cs.data(), (int)cs.size());
         else

@@ -205,3 +205,36 @@ def test_batches_in_flight_equal_synchronous_batches(env):
         assert np.array_equal(h.thresholded(1, (1080, 1920)), thr1)
     finally:
         h.close()
+
+
+def test_gl_modelviews_of_hip_detected_poses(env):
+    """SURVEY §8 row f4 with poses that come from the HIP path (reference test Aruco.GL_Conversion, test/core_tests.cpp:
+    230-283 <-> testdata/board/expected_gl.yml): detect the board image with intrinsics and marker size 1, board pose from
+    BoardDetector, model-view matrices through the per-pose, the n-pose and the batched device entry points."""
+    import json
+    import os
+
+    from tests.util import GOLDEN, rel_err
+    capi = env["capi"]
+    gray, board = load_case("board")
+    gl = json.load(open(os.path.join(GOLDEN, "board_gl.json")))["gldata"]
+    intr, bc = board["intrinsics"], board["board_conf"]
+    h = capi.Handle(640, 480, max_batch=1)
+    try:
+        ms = h.detect(gray, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        assert len(ms) == len(gl) - 2
+        b = h.board_detect(ms, bc["ids"], bc["obj"], bc["info_type"], K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        assert rel_err(capi.gl_modelview(b["rvec"], b["tvec"]), gl[1]) < 1e-4          # north_star pose tolerance
+        L = capi.load()
+        mvn = np.zeros((len(ms), 16))
+        assert L.arucohip_gl_modelview_n(ms.ctypes.data_as(C.c_void_p), len(ms), mvn.ctypes.data_as(C.c_void_p)) == 0
+        batch = h.gl_modelview_batch(1)[0]
+        assert batch.shape == (len(ms), 16)
+        for i, m in enumerate(ms):
+            assert rel_err(mvn[i], gl[2 + i]) < 1e-4, i
+            assert np.array_equal(mvn[i], capi.gl_modelview(m["rvec"], m["tvec"]))
+            assert np.max(np.abs(batch[i] - mvn[i])) < 1e-12                           # device sin / cos vs libm
+        nopose = h.detect(gray)
+        assert L.arucohip_gl_modelview_n(nopose.ctypes.data_as(C.c_void_p), len(nopose), mvn.ctypes.data_as(C.c_void_p)) == capi.E_INVALID
+    finally:
+        h.close()
