@@ -36,6 +36,7 @@ struct ThrArgs {
     int n, n_half;        // b*b and b*b/2
     int tnx, tny;         // tiles per row / column of the tiled binary image
     int fast;             // width, strides and base address are multiples of 4: dword loads and stores (template FAST)
+    int fast16;           // ... multiples of 16 and width >= 16: the 16-pixel-per-lane kernel applies
     uint8_t* thres;
     uint64_t* tiles;
 };
@@ -245,11 +246,201 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass with 16 pixels per lane (blocks up to 9x9, rows 16-byte aligned: the default configuration). A wave owns a
+// 1024-pixel strip: one 16-byte load and one 16-byte non-temporal store per lane and row. The narrow kernel above spends
+// 74 % of its wave time waiting for memory (SQ_WAIT_ANY, profiles/r02_sq_counters_b.txt) with 256 bytes per load in flight and
+// 35 scalar instructions per 256 pixels; here a wave has PF KiB of loads in flight and a quarter of the scalar work per pixel.
+//
+// Vertical first: V = column sums of the last 2R+1 rows, kept per dword as two u16 pairs E = (V[0], V[2]) and O = (V[1], V[3])
+// (the byte pairs `& 0x00FF00FF` and `>> 8 & 0x00FF00FF` of a gray dword), updated with the row that enters and the row that
+// leaves (V + new - old never borrows across the halves). The horizontal 7-sum of a pixel pair is then a sum of pair-aligned
+// neighbours: with XE_d = (E_d.hi, E_d+1.lo) and XO_d likewise (one v_alignbyte each),
+//   C_d = E_d + O_d + XE_d + XO_d + XE_d-1 + XO_d-1,   S(E_d) = C_d + O_d-1,   S(O_d) = C_d + E_d+1        (R = 3)
+// and for other R the window is assembled from the same pieces. Only the gray rows live in a register ring (window + PF
+// rows of prefetch: no ring of horizontal sums), neighbour lanes contribute E / O of their first / last dword through the
+// DPP wave shift, the strip's halo dword keeps its own column sums on the two edge lanes. A lane covers two tile columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int WSTRIP = 1024;    // pixels per wave and row; strips start on 1-KiB boundaries of the row (a 992-pixel strip with
+                                // two halo lanes instead of halo loads was measured: the misaligned 16-byte accesses cost more)
+constexpr uint32_t SEL02 = 0x0C020C00u, SEL13 = 0x0C030C01u;   // v_perm selectors: bytes (0, 2) / (1, 3) of a dword as u16 pairs
+
+template <int R, int PF, int SEGW>
+__global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
+    static_assert(R >= 1 && R <= 4 && PF >= 1 && PF <= 7, "one halo dword per side; the shortest segment has 8 rows");
+    constexpr int RING = 2 * R + 1, N = RING + PF;
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.z;
+    const int W = a.width, H = a.height;
+    const int x = (int)blockIdx.x * WSTRIP + 16 * lane;                        // first pixel of this lane
+    const int ys = (int)blockIdx.y * SEGW, ye = min(ys + SEGW, H);
+    const int ye8 = (ye + 7) & ~7;
+    const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
+    const int plane = frame * a.nthr + a.t;
+    uint8_t* tdst = a.thres + (size_t)plane * W * H;
+    uint64_t* bdst = a.tiles + (size_t)plane * a.tnx * a.tny;
+
+    const bool out_lane = x < W;
+    const bool edge_lane = lane == 0 || lane == 63;
+    const uint32_t xa = (uint32_t)min(x, W - 16);                              // W is a multiple of 16
+    // lanes right of the image replicate the row's last pixel (BORDER_REPLICATE in x): one v_perm per dword takes either the
+    // dword itself or that pixel
+    const uint32_t rep_sel = x >= W ? 0x07070707u : 0x03020100u;
+    // tile-row bits: dwords 0 / 2 give bits 0..3 of their tile's row byte, dwords 1 / 3 bits 4..7; pixels with 1 <= x <= W-2
+    uint32_t rowsel[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        rowsel[d] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x + 4 * d + j >= 1 && x + 4 * d + j <= W - 2) rowsel[d] |= ((d & 1) ? 16u : 1u) << (9 * j);
+    }
+    auto load_row = [&](int r) -> uint4 {
+        const uint8_t* row = src + (size_t)min(max(r, 0), H - 1) * a.row_stride;   // BORDER_REPLICATE in y
+        const uint4 v = *(const uint4*)(row + xa);
+        return make_uint4(__builtin_amdgcn_perm(v.w, v.x, rep_sel), __builtin_amdgcn_perm(v.w, v.y, rep_sel), __builtin_amdgcn_perm(v.w, v.z, rep_sel),
+                          __builtin_amdgcn_perm(v.w, v.w, rep_sel));
+    };
+    // halo: lane 0 fetches the dword left of the strip, lane 63 the dword right of it
+    const int xp = lane == 0 ? x - 4 : x + 16;
+    const uint32_t hxa = (uint32_t)min(max(xp, 0), W - 4);
+    const uint32_t hsel = xp < 0 ? 0x00000000u : (xp >= W ? 0x03030303u : 0x03020100u);
+    auto load_halo = [&](int r) -> uint32_t {
+        uint32_t v = 0;
+        if (edge_lane) {
+            const uint8_t* row = src + (size_t)min(max(r, 0), H - 1) * a.row_stride;
+            v = __builtin_amdgcn_perm(0u, *(const uint32_t*)(row + hxa), hsel);
+        }
+        return v;
+    };
+    auto from_left_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false); };
+    auto from_right_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false); };
+
+    uint4 G[N];
+    uint32_t GH[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) G[k] = make_uint4(0, 0, 0, 0), GH[k] = 0;
+    uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0}, VEh = 0, VOh = 0;
+    uint32_t accA = 0, accB = 0, loA = 0, loB = 0;     // tile rows of the lane's two tile columns, 4 rows per dword
+    const int cstp = a.idelta * a.n - a.n_half - 1;
+    const short2v n2 = {(short)a.n, (short)a.n}, c2 = {(short)cstp, (short)cstp};
+    const int r_begin = ys - R;
+
+    // Step s: gray row r_begin + s enters the window (ring slot s % N), row s - RING leaves it (slot (s + PF) % N, refilled with
+    // row s + PF right after); OLD = there is a row to leave; STEADY = the window is complete, its centre row s - R is thresholded.
+    auto step = [&](const int sn, const int s, const bool has_old, const bool steady) {
+        const int so = (sn + PF) % N, sc = (sn + N - R) % N;
+        const int r = r_begin + s, c = r - R;
+        {
+            const uint32_t nw[4] = {G[sn].x, G[sn].y, G[sn].z, G[sn].w};
+            const uint32_t od[4] = {G[so].x, G[so].y, G[so].z, G[so].w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                VE[d] += __builtin_amdgcn_perm(0u, nw[d], SEL02), VO[d] += __builtin_amdgcn_perm(0u, nw[d], SEL13);
+                if (has_old) VE[d] -= __builtin_amdgcn_perm(0u, od[d], SEL02), VO[d] -= __builtin_amdgcn_perm(0u, od[d], SEL13);
+            }
+            VEh += __builtin_amdgcn_perm(0u, GH[sn], SEL02), VOh += __builtin_amdgcn_perm(0u, GH[sn], SEL13);
+            if (has_old) VEh -= __builtin_amdgcn_perm(0u, GH[so], SEL02), VOh -= __builtin_amdgcn_perm(0u, GH[so], SEL13);
+        }
+        G[so] = load_row(r + PF);
+        GH[so] = load_halo(r + PF);
+        if (!steady) return;
+        // ---- horizontal sums of the column sums: E[d + 1] / O[d + 1] = pairs of dword d, d = -1 (left lane) .. 4 (right lane)
+        uint32_t E[6], O[6];
+        E[0] = from_left_h(VE[3], VEh), O[0] = from_left_h(VO[3], VOh);
+        E[5] = from_right_h(VE[0], VEh), O[5] = from_right_h(VO[0], VOh);
+#pragma unroll
+        for (int d = 0; d < 4; d++) E[d + 1] = VE[d], O[d + 1] = VO[d];
+        // pair (x, x + 2) for every pixel offset: at[4 * (d + 1) + j] = pair that starts at pixel j of dword d
+        auto at = [&](int q) -> uint32_t {   // q = 4 * (dword + 1) + pixel, pixel 0..3
+            const int w = q >> 2, j = q & 3;
+            if (j == 0) return E[w];
+            if (j == 1) return O[w];
+            if (j == 2) return __builtin_amdgcn_alignbyte(E[w + 1], E[w], 2);
+            return __builtin_amdgcn_alignbyte(O[w + 1], O[w], 2);
+        };
+        const uint4 Gc4 = G[sc];
+        const uint32_t Gc[4] = {Gc4.x, Gc4.y, Gc4.z, Gc4.w};
+        uint32_t t4[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            // S(E_d) = pairs starting at pixels -R .. R of the dword, S(O_d) = those starting at 1 - R .. R + 1 (the compiler
+            // shares the common terms and the v_alignbyte results between the two sums and between neighbouring dwords)
+            uint32_t sE = 0, sO = 0;
+#pragma unroll
+            for (int i = -R; i <= R; i++) sE += at(4 * (d + 1) + i), sO += at(4 * (d + 1) + i + 1);
+            const short2v e = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, Gc[d], SEL02));   // g0, g2
+            const short2v o = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, Gc[d], SEL13));   // g1, g3
+            // (g + C) * n - n/2 - 1 - S < 0  <=>  (g + C) * n <= S + n/2
+            const short2v d02 = e * n2 + c2 - __builtin_bit_cast(short2v, sE);
+            const short2v d13 = o * n2 + c2 - __builtin_bit_cast(short2v, sO);
+            // v_perm selectors 8..11 replicate the sign bit of a source's 16-bit halves: 255 where the difference is negative
+            t4[d] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, d13), __builtin_bit_cast(uint32_t, d02), 0x0B090A08u);
+        }
+        if (c < ye && out_lane) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 tv = {t4[0], t4[1], t4[2], t4[3]};
+            __builtin_nontemporal_store(tv, (u32x4*)(tdst + (size_t)c * W + xa));
+        }
+        // ---- binary image for contour purposes, frame cleared: one byte per tile row and tile column
+        const bool rs_on = c >= 1 && c <= H - 2;
+        uint32_t rbA = __builtin_amdgcn_sad_u8(t4[0] & rowsel[0], 0u, __builtin_amdgcn_sad_u8(t4[1] & rowsel[1], 0u, 0u));
+        uint32_t rbB = __builtin_amdgcn_sad_u8(t4[2] & rowsel[2], 0u, __builtin_amdgcn_sad_u8(t4[3] & rowsel[3], 0u, 0u));
+        rbA = rs_on ? rbA : 0u, rbB = rs_on ? rbB : 0u;
+        accA = __builtin_amdgcn_alignbyte(rbA, accA, 1);                       // rows enter at the top byte
+        accB = __builtin_amdgcn_alignbyte(rbB, accB, 1);
+        if ((c & 3) == 3) {
+            if (c & 4) {
+                if (out_lane) {
+                    uint64_t* t = bdst + (size_t)(c >> 3) * a.tnx + (x >> 3);
+                    t[0] = (uint64_t)loA | ((uint64_t)accA << 32);
+                    t[1] = (uint64_t)loB | ((uint64_t)accB << 32);
+                }
+            } else {
+                loA = accA, loB = accB;
+            }
+        }
+    };
+
+    const int s_last = ye8 - 1 + R - r_begin;   // >= 7 + 2R >= N - 1
+    // prologue: PF rows in flight before the first one is used
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        G[k] = load_row(r_begin + k);
+        GH[k] = load_halo(r_begin + k);
+    }
+#pragma unroll
+    for (int s = 0; s < 2 * R; s++) step(s % N, s, false, false);      // the first 2R rows only build the sums
+    step((2 * R) % N, 2 * R, false, true);                               // first complete window
+#pragma unroll
+    for (int s = RING; s < N; s++) step(s % N, s, true, true);          // up to the first whole turn of the ring
+    int s0 = N;
+    for (; s0 + N - 1 <= s_last; s0 += N) {                              // whole turns: straight-line code, slots are constants
+#pragma unroll
+        for (int k = 0; k < N; k++) step(k, s0 + k, true, true);
+    }
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) {
+        if (s0 + k > s_last) return;
+        step(k, s0 + k, true, true);
+    }
+}
+
 template <int R>
 static void launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
     dim3 grid((a.width + STRIP - 1) / STRIP, (a.height + SEG - 1) / SEG, nframes);
     constexpr bool CAN16 = R <= 5;
     const long lim = (long)(256 + abs(a.idelta)) * a.n + a.n_half;
+    static const bool wide_ok = !(getenv("ARUCOHIP_THRESHOLD_WIDE") && atoi(getenv("ARUCOHIP_THRESHOLD_WIDE")) == 0);   // tuning / A-B knob
+    if constexpr (R <= 4) {
+        if (a.fast16 && lim < 32768 && wide_ok) {
+            // prefetch depth 3 rows, 128-row segments: the best of the sweep (PF 2..5, segments 64 / 128 / 256, forced register
+            // budgets; profiles/r02_threshold_sweep.txt: 0.53 ms per 512 frames, everything else 0.54 .. 1.6)
+            dim3 wgrid0((a.width + WSTRIP - 1) / WSTRIP, (a.height + 127) / 128, nframes);
+            hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), wgrid0, dim3(64), 0, s, a);
+            return;
+        }
+    }
     if (!a.fast)
         hipLaunchKernelGGL((threshold_strip_kernel<R, MODE_ADPT, false, false>), grid, dim3(64), 0, s, a);
     else if (CAN16 && lim < 32768)
@@ -265,6 +456,7 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.thres = b.thres, a.tiles = b.tiles;
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.fast = ((g.width | (int)(g.row_stride & 3) | (int)(g.frame_stride & 3) | (int)((uintptr_t)gray & 3)) & 3) == 0;
+    a.fast16 = g.width >= 16 && ((g.width | (int)(g.row_stride & 15) | (int)(g.frame_stride & 15) | (int)((uintptr_t)gray & 15) | (int)((uintptr_t)b.thres & 15)) & 15) == 0;
 }
 
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {

@@ -502,3 +502,29 @@ def test_refine_fail_frame(env):
         _compare_markers(got, ref, pose=True)
     finally:
         h.close()
+
+
+def test_threshold_wide_kernel_strip_edges(env):
+    """The 16-pixel-per-lane threshold kernel (widths that are multiples of 16, blocks up to 9x9): widths around the 1024-pixel
+    strip (one strip exactly, one strip + one lane, two strips, a partly filled second strip), heights that are not multiples
+    of the 128-row segment or of 8, every block size of that kernel, positive and negative C; threshold bytes and contours
+    (which go through the tiles the kernel writes) equal the oracle."""
+    capi, orc = env["capi"], env["orc"]
+    rng = np.random.RandomState(11)
+    h = capi.Handle(2064, 300, max_batch=1)
+    try:
+        for (wid, hgt) in ((1024, 64), (1040, 131), (2048, 40), (2064, 137), (16, 300), (1920, 33), (48, 32)):
+            base = rng.randint(0, 256, size=(hgt // 8 + 2, wid // 8 + 2)).astype(np.float32)
+            g = np.kron(base, np.ones((8, 8), np.float32))[:hgt, :wid] + rng.randint(-20, 21, size=(hgt, wid))
+            g = np.clip(g, 0, 255).astype(np.uint8)
+            if wid >= 32 and hgt >= 32:
+                for block, c in ((7, 7.0), (3, 2.0), (5, -3.0), (9, 11.5)):
+                    got = h.threshold(g, capi.THRES_ADPT, block, c)
+                    exp = orc.adaptive_threshold(g, block, c)
+                    assert np.array_equal(got, exp), (wid, hgt, block, c, int((got != exp).sum()))
+        for (wid, hgt) in ((1040, 131), (2064, 137)):
+            img = blob_image(rng, hgt, wid, 5)
+            g = np.where(img > 0, 40, 200).astype(np.uint8)       # gray frame whose threshold bands are the blob borders
+            _contour_check(env, h, g, False, 0.01, 1.0)
+    finally:
+        h.close()
