@@ -14,6 +14,8 @@ namespace ah {
 
 __host__ __device__ inline int tiles_x(int width) { return (width + 7) / 8 + 1; }
 __host__ __device__ inline int tiles_y(int height) { return (height + 7) / 8 + 1; }
+// 128-tile strips of a tile row (one wave of the wide threshold kernel covers one: 64 lanes x 2 tiles)
+__host__ __device__ inline int tile_strips(int width) { return (width + 1023) / 1024; }
 
 // packed pixel position y << 16 | x; a step in direction d (0=E,1=NE,2=N,3=NW,4=W,5=SW,6=S,7=SE, y down) adds tb_dpos(d)
 __device__ __forceinline__ uint32_t tb_dpos(int d) {

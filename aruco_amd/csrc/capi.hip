@@ -206,7 +206,7 @@ static void free_all(arucohip_handle* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
-    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -280,6 +280,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     const size_t bits_bytes = P * (size_t)tiles_x(lim->max_width) * tiles_y(lim->max_height) * sizeof(uint64_t) + 64;
     ALLOC(b.tiles, bits_bytes);
     if ((e = hipMemset(b.tiles, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad tiles must read as zero
+    ALLOC(b.tile_bits, P * (size_t)tiles_y(lim->max_height) * 2 * tile_strips(lim->max_width) * sizeof(uint64_t));
     h->bits_bytes = bits_bytes;
     ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
     ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));

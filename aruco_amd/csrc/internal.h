@@ -109,6 +109,8 @@ struct DetectParams {
 struct Buffers {
     uint8_t* thres;
     uint64_t* tiles;       // [P][tiles_y(H)][tiles_x(W)] binary image in 8x8-pixel tiles (bits_tiles.h)
+    uint64_t* tile_bits;   // [P][tiles_y(H)][2 * tile_strips(W)] non-empty-tile bitmap: per 128-tile strip one word for the even
+                           // tiles (bit i = tile 128 s + 2 i) and one for the odd ones (tile 128 s + 2 i + 1)
     uint2* raw;            // [P][cap_raw] waypoint cracks per plane (segment mode)
     uint32_t* raw_cnt;     // [P * TRIG_CNT_STRIDE] fill level of each plane's raw list (one counter per 128-byte line)
     uint2* trig;           // [P][cap_trig] candidates that pass the run rule
@@ -155,6 +157,7 @@ void launch_undist_map(hipStream_t s, int W, int H, const float* K, const float*
 void launch_remap(hipStream_t s, const uint8_t* src, size_t row_stride, size_t frame_stride, int W, int H, int cn, int nframes, const short2* xy,
                   const uint16_t* fxy, uint8_t* dst);
 void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);
+void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 struct WalkFork {

@@ -222,7 +222,166 @@ __global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel 1b, sparse form (walker mode): nine tiles in ten are empty and cannot hold a start (a start needs a set pixel in the
+// tile, or in its left or upper neighbour). The threshold kernel leaves a non-empty-tile bitmap (two words per 128-tile
+// strip: even tiles, odd tiles); a wave walks its share of the tile rows on those words alone, queues the tiles that can
+// hold a start and evaluates 64 queued tiles at a time with all lanes busy: the start rule, the run rule on the 16 pixels at
+// hand and — for the few runs that leave them — the 64-pixel run rule at once. Survivors are staged per wave and appended to
+// the plane's lists with one atomic per list and flush.
+// ---------------------------------------------------------------------------------------------
+constexpr int CQ_CAP = 192;       // queued tile ids per wave (a round consumes 64; at most 128 join per strip)
+constexpr int CS_CAP = 256;       // staged survivors per list and wave
+
+struct SparseArgs {
+    const uint64_t* tiles;
+    const uint64_t* tile_bits;
+    int tnx, tny, nstrips;
+    int width, height;
+    uint2* trig;
+    uint32_t* trig_cnt;
+    uint32_t* counters;
+    uint32_t cap_trig;
+};
+
+__global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
+    latency_bound_priority();
+    __shared__ uint32_t s_q[CQ_CAP];
+    __shared__ uint2 s_keep[2][CS_CAP];
+    __shared__ uint32_t s_n[2];
+    const int plane = blockIdx.y, lane = threadIdx.x;
+    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
+    const uint64_t* __restrict__ bits = a.tile_bits + (size_t)plane * a.tny * (2 * a.nstrips);
+    const int ntx = a.tnx - 1, nty = a.tny - 1;          // real tiles
+    const uint32_t half = a.cap_trig / 2;
+    uint2* const out = a.trig + (size_t)plane * a.cap_trig;
+    uint32_t* const out_cnt = a.trig_cnt + plane * TRIG_CNT_STRIDE;
+    const uint64_t COL0 = 0x0101010101010101ull, COL7 = 0x8080808080808080ull;
+    if (lane < 2) s_n[lane] = 0;
+    __syncthreads();
+
+    // staged survivors -> the plane's lists (all lanes call it)
+    auto flush = [&]() {
+        __syncthreads();
+        for (int kind = 0; kind < 2; kind++) {
+            const uint32_t n = min(s_n[kind], (uint32_t)CS_CAP);
+            if (n == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&out_cnt[kind], n);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            for (uint32_t j = lane; j < n; j += WAVE) {
+                if (base + j < half)
+                    out[(size_t)kind * half + base + j] = s_keep[kind][j];
+                else
+                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+            }
+        }
+        __syncthreads();
+        if (lane < 2) s_n[lane] = 0;
+        __syncthreads();
+    };
+    auto stage = [&](int kind, uint2 rec) {
+        const uint32_t ls = atomicAdd(&s_n[kind], 1u);
+        if (ls < CS_CAP) {
+            s_keep[kind][ls] = rec;
+        } else {   // the staging list is full: straight to the plane's list
+            const uint32_t slot = atomicAdd(&out_cnt[kind], 1u);
+            if (slot < half)
+                out[(size_t)kind * half + slot] = rec;
+            else
+                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+        }
+    };
+    // one queued tile per lane
+    auto evaluate = [&](bool live, uint32_t id) {
+        if (live) {
+            const int ty = (int)(id >> 16), tx = (int)(id & 0xFFFFu);
+            const uint64_t* t = tiles + (size_t)ty * a.tnx + tx;
+            const uint64_t T = t[0];
+            const uint64_t L = tx > 0 ? t[-1] : 0ull;
+            const uint64_t U = ty > 0 ? t[-a.tnx] : 0ull, UL = (ty > 0 && tx > 0) ? t[-a.tnx - 1] : 0ull, UR = ty > 0 ? t[-a.tnx + 1] : 0ull;
+            const uint64_t Rt = t[1];
+            const uint64_t Wn = ((T << 1) & ~COL0) | ((L >> 7) & COL0);
+            const uint64_t N = (T << 8) | (U >> 56), NLt = (L << 8) | (UL >> 56), NRt = (Rt << 8) | (UR >> 56);
+            const uint64_t NW = ((N << 1) & ~COL0) | ((NLt >> 7) & COL0);
+            const uint64_t NE = ((N >> 1) & ~COL7) | ((NRt << 7) & COL7);
+            const int jmax = a.width - 2 - 8 * tx, imax = a.height - 2 - 8 * ty;
+            const uint64_t colm = (jmax >= 7 ? 0xFFull : (jmax < 0 ? 0ull : ((1ull << (jmax + 1)) - 1ull))) * COL0;
+            const uint64_t rowm = imax >= 7 ? ~0ull : (imax < 0 ? 0ull : ((1ull << (8 * (imax + 1))) - 1ull));
+            const uint64_t outer = T & ~(Wn | NW | N | NE);
+            const uint64_t hole = ~T & Wn & N & colm & rowm;
+            const uint32_t base = ((uint32_t)(8 * ty) << 16) | (uint32_t)(8 * tx);
+            uint64_t m = outer | hole;
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int q = b >> 3, j = b & 7;
+                const uint32_t kind = (uint32_t)(hole >> b) & 1u;
+                const uint32_t mid = ((((uint32_t)(T >> (8 * q)) & 0xFFu) | (((uint32_t)(Rt >> (8 * q)) & 0xFFu) << 8)) >> j);
+                const uint32_t up = ((((uint32_t)(N >> (8 * q)) & 0xFFu) | (((uint32_t)(NRt >> (8 * q)) & 0xFFu) << 8)) >> j);
+                const int avail = 16 - j;
+                const uint32_t pos = base + ((uint32_t)q << 16) + (uint32_t)j;
+                const uint32_t runbits = (kind ? mid : ~mid) | (1u << avail);
+                const int Lr = __builtin_ctz(runbits);
+                const int hi = kind ? min(Lr - 1, avail - 1) : min(Lr, avail - 1);
+                const uint32_t span = ((2u << hi) - 1u) & (kind ? ~1u : ~3u);
+                if (((kind ? ~up : up) & span) != 0) continue;
+                // a run that leaves the 16 pixels at hand takes the 64-pixel test at once (rare)
+                if (Lr < avail || run_rule_tiles(tiles, a.tnx, (int)(pos & 0xFFFFu), (int)(pos >> 16), (int)kind)) stage((int)kind, make_uint2(kind, pos));
+            }
+        }
+        __syncthreads();
+        if (max(s_n[0], s_n[1]) > CS_CAP - 64) flush();   // wave-uniform: room for another round's typical yield
+    };
+
+    uint32_t qn = 0;   // queued tiles (wave-uniform)
+    for (int ty = blockIdx.x; ty < nty; ty += gridDim.x) {
+        for (int st = 0; st < a.nstrips; st++) {
+            const uint64_t* w = bits + (size_t)ty * (2 * a.nstrips) + 2 * st;
+            const uint64_t A = w[0], Bm = w[1];
+            const uint64_t UA = ty > 0 ? w[-2 * a.nstrips] : 0ull, UB = ty > 0 ? w[-2 * a.nstrips + 1] : 0ull;
+            const uint64_t carry = st > 0 ? (w[-1] >> 63) : 0ull;          // the previous strip's last (odd) tile
+            // a tile can hold a start if it, its left or its upper neighbour holds a pixel
+            const uint64_t needA = A | (Bm << 1) | carry | UA, needB = Bm | A | UB;
+#pragma unroll
+            for (int odd = 0; odd < 2; odd++) {
+                const uint64_t need = odd ? needB : needA;
+                const int tx = 128 * st + 2 * lane + odd;
+                const bool act = ((need >> lane) & 1ull) && tx < ntx;
+                const unsigned long long bal = __ballot(act);
+                if (bal) {
+                    if (act) s_q[qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)ty << 16) | (uint32_t)tx;
+                    qn += (uint32_t)__popcll(bal);
+                    __syncthreads();
+                    if (qn >= 128) {   // keep room for the next 64 joins
+                        while (qn >= 64) {
+                            qn -= 64;
+                            evaluate(true, s_q[qn + lane]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    while (qn >= 64) {
+        qn -= 64;
+        evaluate(true, s_q[qn + lane]);
+    }
+    if (qn > 0) evaluate((uint32_t)lane < qn, (uint32_t)lane < qn ? s_q[lane] : 0u);
+    flush();
+}
+
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
+    static const bool sparse_ok = !(getenv("ARUCOHIP_CAND_SPARSE") && atoi(getenv("ARUCOHIP_CAND_SPARSE")) == 0);   // A-B knob
+    if (!b.seg_mode && sparse_ok) {
+        SparseArgs a;
+        a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.nstrips = tile_strips(g.width);
+        a.width = g.width, a.height = g.height, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
+        const int nty = a.tny - 1;
+        const int waves = getenv("ARUCOHIP_CAND_WAVES") ? std::max(1, atoi(getenv("ARUCOHIP_CAND_WAVES"))) : 32;   // waves per plane (tuning knob: 4 0.25, 8 0.18, 16 0.13, 32 0.13 ms per 512 frames)
+        hipLaunchKernelGGL(candidates_sparse_kernel, dim3(std::min(waves, nty), nplanes), dim3(64), 0, s, a);
+        return;
+    }
     CandArgs a;
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
     a.width = g.width, a.height = g.height;

@@ -39,6 +39,8 @@ struct ThrArgs {
     int fast16;           // ... multiples of 16 and width >= 16: the 16-pixel-per-lane kernel applies
     uint8_t* thres;
     uint64_t* tiles;
+    uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
+    int nstrips;          // 128-tile strips per tile row
 };
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -396,6 +398,13 @@ __global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
                     t[0] = (uint64_t)loA | ((uint64_t)accA << 32);
                     t[1] = (uint64_t)loB | ((uint64_t)accB << 32);
                 }
+                // which of the strip's 128 tiles hold a pixel: the start-candidate kernel only visits those (and their
+                // right / lower neighbours)
+                const unsigned long long balA = __ballot(out_lane && (loA | accA) != 0u), balB = __ballot(out_lane && (loB | accB) != 0u);
+                if (lane == 0) {
+                    uint64_t* bw = a.tile_bits + ((size_t)plane * a.tny + (c >> 3)) * (2 * a.nstrips) + 2 * blockIdx.x;
+                    bw[0] = balA, bw[1] = balB;
+                }
             } else {
                 loA = accA, loB = accB;
             }
@@ -426,8 +435,28 @@ __global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
     }
 }
 
+// the non-empty-tile bitmap for the paths whose kernel does not write it (narrow / FIXED / caller-supplied binary image): one
+// wave per (strip, tile row, plane) reads the strip's 128 tiles
+__global__ __launch_bounds__(64) void tile_bitmap_kernel(const uint64_t* __restrict__ tiles, uint64_t* __restrict__ tile_bits, int tnx, int tny, int nstrips) {
+    const int strip = blockIdx.x, ty = blockIdx.y, plane = blockIdx.z, lane = threadIdx.x;
+    const uint64_t* row = tiles + ((size_t)plane * tny + ty) * tnx;
+    const int tx = 128 * strip + 2 * lane;
+    const uint64_t A = tx < tnx ? row[tx] : 0ull, B = tx + 1 < tnx ? row[tx + 1] : 0ull;
+    const unsigned long long balA = __ballot(A != 0ull), balB = __ballot(B != 0ull);
+    if (lane == 0) {
+        uint64_t* bw = tile_bits + ((size_t)plane * tny + ty) * (2 * nstrips) + 2 * strip;
+        bw[0] = balA, bw[1] = balB;
+    }
+}
+
+void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
+    const int tnx = tiles_x(g.width), tny = tiles_y(g.height), ns = tile_strips(g.width);
+    hipLaunchKernelGGL(tile_bitmap_kernel, dim3(ns, tny, nplanes), dim3(64), 0, s, b.tiles, b.tile_bits, tnx, tny, ns);
+}
+
+// returns true if the kernel that ran also wrote the non-empty-tile bitmap
 template <int R>
-static void launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
+static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
     dim3 grid((a.width + STRIP - 1) / STRIP, (a.height + SEG - 1) / SEG, nframes);
     constexpr bool CAN16 = R <= 5;
     const long lim = (long)(256 + abs(a.idelta)) * a.n + a.n_half;
@@ -438,7 +467,7 @@ static void launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
             // budgets; profiles/r02_threshold_sweep.txt: 0.53 ms per 512 frames, everything else 0.54 .. 1.6)
             dim3 wgrid0((a.width + WSTRIP - 1) / WSTRIP, (a.height + 127) / 128, nframes);
             hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), wgrid0, dim3(64), 0, s, a);
-            return;
+            return true;
         }
     }
     if (!a.fast)
@@ -447,19 +476,21 @@ static void launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
         hipLaunchKernelGGL((threshold_strip_kernel<R, MODE_ADPT, CAN16, true>), grid, dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((threshold_strip_kernel<R, MODE_ADPT, false, true>), grid, dim3(64), 0, s, a);
+    return false;
 }
 
 static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const Buffers& b, int nthr, int t) {
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
     a.width = g.width, a.height = g.height, a.nthr = nthr, a.t = t;
     a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
-    a.thres = b.thres, a.tiles = b.tiles;
+    a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width);
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.fast = ((g.width | (int)(g.row_stride & 3) | (int)(g.frame_stride & 3) | (int)((uintptr_t)gray & 3)) & 3) == 0;
     a.fast16 = g.width >= 16 && ((g.width | (int)(g.row_stride & 15) | (int)(g.frame_stride & 15) | (int)((uintptr_t)gray & 15) | (int)((uintptr_t)b.thres & 15)) & 15) == 0;
 }
 
 void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+    bool bitmap_done = true;
     for (int t = 0; t < p.nthr; t++) {
         ThrArgs a;
         fill_args(a, gray, g, b, p.nthr, t);
@@ -470,27 +501,29 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
                 hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_FIXED, false, true>), grid, dim3(64), 0, s, a);
             else
                 hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_FIXED, false, false>), grid, dim3(64), 0, s, a);
+            bitmap_done = false;
             continue;
         }
         a.n = p.block[t] * p.block[t], a.n_half = a.n / 2, a.idelta = p.idelta;
         switch (p.block[t] / 2) {
-            case 1: launch_adpt<1>(s, a, nframes); break;
-            case 2: launch_adpt<2>(s, a, nframes); break;
-            case 3: launch_adpt<3>(s, a, nframes); break;
-            case 4: launch_adpt<4>(s, a, nframes); break;
-            case 5: launch_adpt<5>(s, a, nframes); break;
-            case 6: launch_adpt<6>(s, a, nframes); break;
-            case 7: launch_adpt<7>(s, a, nframes); break;
-            case 8: launch_adpt<8>(s, a, nframes); break;
-            case 9: launch_adpt<9>(s, a, nframes); break;
-            case 10: launch_adpt<10>(s, a, nframes); break;
-            case 11: launch_adpt<11>(s, a, nframes); break;
-            case 12: launch_adpt<12>(s, a, nframes); break;
-            case 13: launch_adpt<13>(s, a, nframes); break;
-            case 14: launch_adpt<14>(s, a, nframes); break;
-            default: launch_adpt<15>(s, a, nframes); break;
+            case 1: bitmap_done &= launch_adpt<1>(s, a, nframes); break;
+            case 2: bitmap_done &= launch_adpt<2>(s, a, nframes); break;
+            case 3: bitmap_done &= launch_adpt<3>(s, a, nframes); break;
+            case 4: bitmap_done &= launch_adpt<4>(s, a, nframes); break;
+            case 5: bitmap_done &= launch_adpt<5>(s, a, nframes); break;
+            case 6: bitmap_done &= launch_adpt<6>(s, a, nframes); break;
+            case 7: bitmap_done &= launch_adpt<7>(s, a, nframes); break;
+            case 8: bitmap_done &= launch_adpt<8>(s, a, nframes); break;
+            case 9: bitmap_done &= launch_adpt<9>(s, a, nframes); break;
+            case 10: bitmap_done &= launch_adpt<10>(s, a, nframes); break;
+            case 11: bitmap_done &= launch_adpt<11>(s, a, nframes); break;
+            case 12: bitmap_done &= launch_adpt<12>(s, a, nframes); break;
+            case 13: bitmap_done &= launch_adpt<13>(s, a, nframes); break;
+            case 14: bitmap_done &= launch_adpt<14>(s, a, nframes); break;
+            default: bitmap_done &= launch_adpt<15>(s, a, nframes); break;
         }
     }
+    if (!bitmap_done) launch_tile_bitmap(s, g, nframes * p.nthr, b);
 }
 
 // Optional erosion (north_star; off by default, no reference counterpart in this snapshot): 3x3 minimum of the thresholded
@@ -532,6 +565,7 @@ void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeo
         hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_BINARY, false, true>), grid, dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((threshold_strip_kernel<0, MODE_BINARY, false, false>), grid, dim3(64), 0, s, a);
+    launch_tile_bitmap(s, g, nframes, b);
 }
 
 }  // namespace ah
