@@ -207,7 +207,7 @@ static void free_all(arucohip_handle* h) {
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
-    hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers);
+    hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
     hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
@@ -315,6 +315,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.othr, (size_t)b.cap_flat * sizeof(int32_t));
     ALLOC(b.markers, F * b.cap_markers * sizeof(arucohip_marker_t));
     ALLOC(b.nmarkers, F * sizeof(int32_t));
+    ALLOC(b.marker_list, F * (size_t)b.cap_markers * sizeof(uint32_t));
     ALLOC(b.counters, (CNT_FIXED + F) * sizeof(uint32_t));
     ALLOC(h->d_small_f, 8192 * sizeof(float));
     ALLOC(h->d_small_d, 64 * sizeof(double));

@@ -27,7 +27,7 @@ constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
 
 enum Counter {
-    CNT_UNUSED0 = 0,
+    CNT_NMARK = 0,     // entries of the flat marker list (all frames)
     CNT_UNUSED1 = 1,
     CNT_UNUSED2 = 2,
     CNT_STATUS = 3,    // overflow bit flags
@@ -136,6 +136,7 @@ struct Buffers {
     uint32_t cap_flat;
     arucohip_marker_t* markers;
     int32_t* nmarkers;     // [F]
+    uint32_t* marker_list; // flat list over all frames: frame << 16 | index, counters[CNT_NMARK] entries (the pose kernel's work list)
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;   // per plane
     uint32_t long_cap;            // checkpoint rings (long walks) per plane and kind

@@ -27,6 +27,7 @@ struct FinalArgs {
     arucohip_marker_t* markers;
     int32_t* nmarkers;
     uint32_t* counters;
+    uint32_t* marker_list;
     int cap_cands, cap_markers;
     int bx0, by0, bx1, by1;
 };
@@ -94,49 +95,70 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
         }
         if (n > a.cap_markers) atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_MARKER_OVERFLOW);
         a.nmarkers[frame] = n;   // required count; the host clamps and reports ARUCOHIP_E_CAPACITY
+        // work list of the pose kernel (order across frames is irrelevant); never more than F * cap_markers entries
+        const int kept = min(n, a.cap_markers);
+        if (kept > 0) {
+            const uint32_t base = atomicAdd(&a.counters[CNT_NMARK], (uint32_t)kept);
+            for (int i = 0; i < kept; i++) a.marker_list[base + i] = ((uint32_t)frame << 16) | (uint32_t)i;
+        }
     }
 }
 
 void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
     FinalArgs a;
-    a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters;
+    a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters, a.marker_list = b.marker_list;
     a.cap_cands = b.cap_cands, a.cap_markers = b.cap_markers;
     a.bx0 = p.bx0, a.by0 = p.by0, a.bx1 = p.bx1, a.by1 = p.by1;
     hipLaunchKernelGGL(finalize_kernel, dim3(nframes), dim3(64), 0, s, a);
 }
 
-// one lane per marker: solvePnP on the 4 corners against the marker's own square
-__device__ inline void marker_pose(arucohip_marker_t* m, const CamModel& cam) {
-    float hs = (float)((double)cam.marker_size / 2.);
-    float obj[12] = {-hs, -hs, 0, -hs, hs, 0, hs, hs, 0, hs, -hs, 0};
+// Per-marker pose (markerdetector.cpp:450-467, Marker::calculateExtrinsics marker.cpp:112-124): solvePnP of the 4 corners
+// against the marker's own square. Four lanes share a marker — one corner each for the homography sums, the Jacobian rows
+// and the reprojection errors, butterfly sums inside the group of four, the small solves redundantly on every lane — and
+// the markers come from the flat list finalize_kernel wrote, so a wave carries 16 live markers instead of the few slots of
+// one frame that happen to be filled (round 1: one lane per marker slot, 2.0 ms per 20 k markers).
+constexpr int POSE_G = 4;
+
+__device__ inline void marker_pose4(arucohip_marker_t* m, const CamModel& cam, float* s_obj, float* s_img, int sub) {
+    const float hs = (float)((double)cam.marker_size / 2.);
+    // getObjectPoints (marker.cpp:91-108): (-,-), (-,+), (+,+), (+,-)
+    s_obj[3 * sub] = (sub < 2) ? -hs : hs, s_obj[3 * sub + 1] = (sub == 1 || sub == 2) ? hs : -hs, s_obj[3 * sub + 2] = 0.f;
+    s_img[2 * sub] = m->corners[2 * sub], s_img[2 * sub + 1] = m->corners[2 * sub + 1];
     double r[3], t[3];
-    bool ok = solve_pnp_planar(obj, m->corners, 4, cam, r, t);
+    const bool ok = solve_pnp_planar_wave<POSE_G>(s_obj, s_img, 4, cam, r, t, sub);
     if (ok && cam.y_perp) rotate_x_axis(r);
-    for (int k = 0; k < 3; k++) m->rvec[k] = ok ? r[k] : 0, m->tvec[k] = ok ? t[k] : 0;
-    m->has_pose = ok ? 1 : 0;
-    m->ssize = cam.marker_size;
+    if (sub == 0) {
+        for (int k = 0; k < 3; k++) m->rvec[k] = ok ? r[k] : 0, m->tvec[k] = ok ? t[k] : 0;
+        m->has_pose = ok ? 1 : 0;
+        m->ssize = cam.marker_size;
+    }
 }
 
-__global__ __launch_bounds__(64) void pose_kernel(arucohip_marker_t* markers, const int32_t* nmarkers, int cap_markers, int nframes, CamModel cam) {
+// list != nullptr: the batch's flat marker list; else markers[0 .. n_direct)
+__global__ __launch_bounds__(64) void pose_kernel(arucohip_marker_t* markers, const uint32_t* list, const uint32_t* counters, uint32_t cap_list,
+                                                  int cap_markers, int n_direct, CamModel cam) {
     latency_bound_priority();
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int frame = gid / cap_markers, i = gid - frame * cap_markers;
-    if (frame >= nframes || i >= min(nmarkers[frame], cap_markers)) return;
-    marker_pose(markers + (size_t)frame * cap_markers + i, cam);
+    __shared__ float s_obj[16][12], s_img[16][8];
+    const int grp = threadIdx.x / POSE_G, sub = threadIdx.x % POSE_G;
+    const uint32_t gid = blockIdx.x * (64 / POSE_G) + grp;
+    const uint32_t n = list ? min(counters[CNT_NMARK], cap_list) : (uint32_t)n_direct;
+    if (gid >= n) return;   // uniform within the group of four
+    arucohip_marker_t* m = markers + gid;
+    if (list) {
+        const uint32_t e = list[gid];
+        m = markers + (size_t)(e >> 16) * cap_markers + (e & 0xFFFFu);
+    }
+    marker_pose4(m, cam, s_obj[grp], s_img[grp], sub);
 }
 
 void launch_pose(hipStream_t s, int nframes, const CamModel& cam, const Buffers& b) {
-    int total = nframes * b.cap_markers;
-    hipLaunchKernelGGL(pose_kernel, dim3((total + 63) / 64), dim3(64), 0, s, b.markers, b.nmarkers, b.cap_markers, nframes, cam);
-}
-
-__global__ __launch_bounds__(64) void marker_pose_kernel(arucohip_marker_t* markers, int n, CamModel cam) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) marker_pose(markers + i, cam);
+    // the list's length is only known on the device: the grid covers its capacity, surplus workgroups exit at once
+    const uint32_t cap_list = (uint32_t)nframes * (uint32_t)b.cap_markers;
+    hipLaunchKernelGGL(pose_kernel, dim3((cap_list + 15) / 16), dim3(64), 0, s, b.markers, b.marker_list, b.counters, cap_list, b.cap_markers, 0, cam);
 }
 
 void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const CamModel& cam) {
-    hipLaunchKernelGGL(marker_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, markers, n, cam);
+    hipLaunchKernelGGL(pose_kernel, dim3((n + 15) / 16), dim3(64), 0, s, markers, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, n, cam);
 }
 
 // generic planar PnP over npts correspondences (board pose): a single lane, everything in private memory
