@@ -304,3 +304,14 @@ def board_detect(markers, ids, obj, info_type, K, dist, marker_size, repj_thres=
                                   int(bool(y_perp)), out, C.byref(nout), r, t, C.byref(hp))
     return {"prob": float(prob), "markers": [marker_dict(out[i]) for i in range(nout.value)], "rvec": np.array(r),
             "tvec": np.array(t), "has_pose": hp.value}
+
+
+def otsu(img):
+    a, ap = _u8(img)
+    return int(lib().orc_otsu(ap, a.size))
+
+
+def rotate_x_axis(rvec):
+    r = (C.c_double * 3)(*[float(v) for v in rvec])
+    lib().orc_rotate_x_axis(r)
+    return np.array(r)
