@@ -25,11 +25,14 @@ using namespace ah;
 enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_COUNT };
 static const char* kStageNames[STAGE_COUNT] = {"Threshold", "Rectangles", "Identify", "Subpixel", "Filtering"};
 // one event after every kernel of a batch; a ring of TSETS batches so that asynchronous steps can be averaged
-enum { K_THRESHOLD = 0, K_FILTER, K_WALKERS, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
-static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "candidates_kernel", "walker_kernel", "contour_quad_kernel", "frame_candidates_kernel",
-                                            "decode_kernel", "refine_lines_kernel", "refine_pixels_kernel", "finalize_kernel", "pose_kernel"};
-static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_IDENTIFY,
-                                          STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_FILTERING};
+// slot k = the interval between mark k and mark k + 1. walker_long = the generations of long walks up to the fork of the side
+// stream; contour_quad = both passes including the wait for the side stream's late generations.
+enum { K_THRESHOLD = 0, K_FILTER, K_WALKERS, K_WALKERS_LONG, K_CONTOUR_QUADS, K_FRAME_CANDS, K_DECODE, K_REFINE_LINES, K_REFINE_PIXELS, K_FINALIZE, K_POSE, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"threshold_kernel", "candidates_kernel", "walker_kernel", "walker_long_kernel", "contour_quad_kernel",
+                                            "frame_candidates_kernel", "decode_kernel", "refine_lines_kernel", "refine_pixels_kernel", "finalize_kernel",
+                                            "pose_kernel"};
+static const int kKernelStage[K_COUNT] = {STAGE_THRESHOLD, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES, STAGE_RECTANGLES,
+                                          STAGE_IDENTIFY, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_FILTERING};
 constexpr int TSETS = 32;
 
 struct arucohip_handle {
@@ -286,8 +289,11 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
     {
+        // contour pipeline: ARUCOHIP_CONTOURS = walkers | segments; default by handle shape. The per-candidate walkers win on
+        // batches; a single small frame is a chain of up to max-contour dependent border steps for them, which the waypoint
+        // segments cut (bench.py latency leg, 1000 calls: 640x480 stills 0.67-0.72 ms vs 0.49-0.52 ms; 1080p 0.89 vs 0.91)
         const char* mode = getenv("ARUCOHIP_CONTOURS");
-        b.seg_mode = (mode && std::string(mode) == "segments");   // default: walkers (faster at large batches)
+        b.seg_mode = mode ? std::string(mode) == "segments" : (lim->max_batch == 1 && (long)lim->max_width * lim->max_height <= 1024L * 768L);
         const char* gs = getenv("ARUCOHIP_GRID");
         int grid = gs ? atoi(gs) : 16;
         if (grid != 1 && grid != 2 && grid != 4 && grid != 8 && grid != 16 && grid != 32) grid = 8;
@@ -596,7 +602,7 @@ static int user_decode_stage(arucohip_handle* h, const DetectParams& dp) {
 
 static void run_walkers_and_quads(arucohip_handle* h, hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& dp) {
     static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
-    WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin};
+    WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, nullptr};
     const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, h->buf);
     launch_contour_quads(s, g, nframes, dp, h->buf, forked ? 1 : 0);
     if (forked) {
@@ -638,7 +644,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
-    MARK(0);
+    MARK(K_THRESHOLD);
     if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));
     launch_threshold(s, gray_dev, g, nframes, dp, b);
     if (h->params.erode) {
@@ -647,51 +653,49 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         launch_erode(s, g, nframes * dp.nthr, b, h->d_erode);
     }
     if (h->ev_thr) HIPCHK(h, hipEventRecord(h->ev_thr, s));
-    MARK(1);
+    MARK(K_FILTER);
     if (b.seg_mode) {
         HIPCHK(h, hipMemsetAsync(b.hash, 0xFF, (size_t)nframes * dp.nthr * (b.hash_mask + 1) * sizeof(uint32_t), s));
         launch_start_candidates(s, g, nframes * dp.nthr, b);
-        MARK(2);
+        MARK(K_WALKERS);
         launch_segments(s, g, nframes * dp.nthr, dp, b);
-    } else {
-        launch_start_candidates(s, g, nframes * dp.nthr, b);
-        MARK(2);
-    }
-    if (b.seg_mode) {
-        MARK(3);
+        MARK(K_WALKERS_LONG);
+        MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b);
     } else {
-        // walkers; their late generations run on the side stream under the first quad pass (MARK(3) sits at the fork)
+        launch_start_candidates(s, g, nframes * dp.nthr, b);
+        MARK(K_WALKERS);
+        // walkers; their late generations run on the side stream under the first quad pass (the contour_quad mark sits at the fork)
         static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
-        WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin};
+        WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};
         const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, b);
-        MARK(3);
+        MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
         if (forked) {
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
             launch_contour_quads(s, g, nframes, dp, b, 2);
         }
     }
-    MARK(4);
+    MARK(K_FRAME_CANDS);
     launch_frame_candidates(s, g, nframes, dp, b);
-    MARK(5);
+    MARK(K_DECODE);
     launch_decode(s, gray_dev, g, nframes, dp, b);
     if (dp.decoder == ARUCOHIP_DECODER_USER) {
         const int rc_ = user_decode_stage(h, dp);
         if (rc_) return rc_;
     }
-    MARK(6);
+    MARK(K_REFINE_LINES);
     launch_refine_lines(s, g, nframes, dp, cam, b);
-    MARK(7);
+    MARK(K_REFINE_PIXELS);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX) {
         if (dp.locked) launch_locked_corners(s, gray_dev, g, nframes, dp, b);   // markerdetector.cpp:398-399
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
     }
-    MARK(8);
+    MARK(K_FINALIZE);
     launch_finalize(s, g, nframes, dp, cam, b);
-    MARK(9);
+    MARK(K_POSE);
     if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
-    MARK(10);
+    MARK(K_COUNT);
 #undef MARK
     if (tm) h->tsets++;
     HIPCHK(h, hipGetLastError());

@@ -164,6 +164,7 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
 struct WalkFork {
     hipStream_t side;            // stream of the late walker generations (nullptr: everything on the main stream)
     hipEvent_t forked, joined;
+    hipEvent_t after_first;      // recorded behind the first pass (per-kernel timing), may be null
 };
 bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 size_t walk_scratch_words(int nplanes, const DetectParams& p, uint32_t long_cap);   // capacity launch_walkers needs in Buffers::walk_scratch

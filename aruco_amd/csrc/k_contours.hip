@@ -744,6 +744,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     const int planes8 = ((nplanes + 7) / 8) * 8;
     // a 64-thread workgroup per wave keeps the divergent walks of one wave from holding other waves' slots
     hipLaunchKernelGGL(walker_kernel, dim3(planes8 * WALK_BLOCKS), dim3(64), 0, s, a);
+    if (fk.after_first) (void)hipEventRecord(fk.after_first, s);
     // Generations: 64-step ones while many walks are alive, then doubling. The late generations hold a handful of very long
     // walks and are pure latency (a border of n pixels is a chain of n dependent steps), so they run on the side stream
     // while the main stream already turns the borders found so far into quads (launch_contour_quads pass 1); the per-plane

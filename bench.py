@@ -68,6 +68,45 @@ def cpu_baseline(frames_host, seconds_single=8.0, seconds_multi=12.0):
             "single_thread_fps": round(single, 2)}
 
 
+def latency_leg(capi, frame_1080p, runs=1000, cpu_seconds=1.5):
+    """The reference's own performance methodology (test/perf_tests.cpp:31-56): detect() on a single gray still held in host
+    memory, mean wall-clock ms over `runs` calls — arucohip_detect including the H2D of the frame and the D2H of the markers.
+    The three 640x480 stills the reference's tests use plus one of the bench's 1080p frames; both contour pipelines of the
+    library (per-candidate walkers, the default, and waypoint segments); the CPU restatement's ms beside it (1 thread)."""
+    import numpy as np
+
+    from aruco_amd.fixtures import load_case
+    from oracle import orc
+
+    stills = [(n, load_case(n)[0]) for n in ("single", "board", "chessboard")] + [("synthetic_1080p", np.ascontiguousarray(frame_1080p))]
+    out = {"method": "mean ms of %d arucohip_detect calls on one host frame (perf_tests.cpp:31-56), cpu = oracle restatement, 1 thread" % runs}
+    o = orc.Oracle()
+    for name, g in stills:
+        row = {}
+        for mode in ("walkers", "segments"):
+            os.environ["ARUCOHIP_CONTOURS"] = mode
+            h = capi.Handle(g.shape[1], g.shape[0], max_batch=1)
+            try:
+                for _ in range(20):
+                    got = h.detect(g)
+                t0 = time.perf_counter()
+                for _ in range(runs):
+                    h.detect(g)
+                row[mode + "_ms"] = round((time.perf_counter() - t0) / runs * 1e3, 4)
+                row["markers"] = len(got)
+            finally:
+                h.close()
+        os.environ.pop("ARUCOHIP_CONTOURS", None)
+        o.detect_raw(g)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < cpu_seconds:
+            o.detect_raw(g)
+            n += 1
+        row["cpu_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+        out[name] = row
+    return out
+
+
 def launch_ranks(n):
     """Plain `python bench.py --gpus N`: this process has not touched the GPU (no torch import yet). Start N fresh rank
     processes with torch.distributed.run on 127.0.0.1, forward what they print (their one JSON line to stdout, everything
@@ -150,9 +189,10 @@ def main():
                     help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
-    ap.add_argument("--depth", type=int, default=3,
+    ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
 
@@ -192,7 +232,7 @@ def main():
             args.frames = 128       # 4K frames are 4x larger; 128 distinct frames per GPU by default
         if args.batch == 1024:
             args.batch = 128
-        from tests.util import load_case
+        from aruco_amd.fixtures import load_case
         _, doc = load_case("board")
         board = doc["board_conf"]
         K0 = np.array(doc["intrinsics"]["K"], np.float32).reshape(3, 3)   # CameraParameters::resize rule to 4K
@@ -286,6 +326,18 @@ def main():
     ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams over the timed steps
     chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
     handle.enable_timing(False)
+    # Outside the timed region: the same kernels one batch at a time. With batches in flight a kernel's event interval also
+    # contains the time it shares the chip with the other batch's kernels; the isolated durations are what rocprofv3 shows
+    # per dispatch when nothing else runs.
+    ktimes_iso = ktimes
+    if depth > 1:
+        handle.enable_timing(True)
+        for i in range(3):
+            t = handle.submit_device(frames_host[0].data_ptr() if frames_host is not None else frames[0].data_ptr(), B, W, H, outs[0].data_ptr(), CAP,
+                                     cnts[0].data_ptr(), K=K, dist=dcoef, marker_size=msize, frames_on_device=frames_host is None)
+            handle.wait(t)
+        ktimes_iso = handle.kernel_times()
+        handle.enable_timing(False)
 
     # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
     n_host = cnts[last["slot"]].cpu().numpy()
@@ -310,15 +362,19 @@ def main():
         dom = max(ktimes, key=lambda k: ktimes[k])
         dom_ms = ktimes[dom]
         achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes of the dominant kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
+        # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if dom in tj.get("kernels", {}):
                     traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * per_launch
+                    traffic_src = "profiles/hbm_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, replayed" % tj.get("tag", "")
             except Exception:
                 traffic = None
+        iso_ms = ktimes_iso.get(dom, dom_ms)
         res = {
             "metric": "frames/sec at %d\u00d7%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -332,15 +388,26 @@ def main():
                        + (", RCCL gather of marker blocks per step" if world > 1 else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
+            # frac: SURVEY §8d recipe (3 W H bytes per frame) over the kernel's event interval in the timed region — with batches in
+            # flight that interval includes sharing the chip with the other batch. frac_isolated: the same over the kernel's
+            # duration when one batch runs alone. frac_own_bytes: the bytes the kernel itself moves (PMC) over that isolated
+            # duration. frac_pipeline: algorithmic bytes of all frames over the whole step.
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * per_launch, "frames_per_launch": per_launch,
-                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4)},
+                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4), "isolated_launch_ms": round(iso_ms, 4),
+                         "frac_isolated": round(ALG_BYTES_PER_FRAME * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
+                         "frac_own_bytes": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
+                         "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5)},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ktimes.items()},
+            "kernel_ms_isolated": {k: round(v, 4) for k, v in ktimes_iso.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             nsample = min(32, args.frames)
             res["cpu_baseline"] = cpu_baseline(frames[:nsample].cpu().numpy())
+        if world == 1 and not args.no_latency and args.config != 4:
+            handle.set_pipeline_depth(0) if depth > 1 else None      # free the lanes' memory before the small handles
+            res["latency"] = latency_leg(capi, frames[0].cpu().numpy())
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -4,21 +4,7 @@ import os
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def read_pgm(path):
-    with open(path, "rb") as f:
-        assert f.readline().strip() == b"P5"
-        w, h = map(int, f.readline().split())
-        f.readline()
-        return np.frombuffer(f.read(), np.uint8).reshape(h, w).copy()
-
-
-def load_case(name):
-    doc = json.load(open(os.path.join(GOLDEN, name + ".json")))
-    gray = read_pgm(os.path.join(GOLDEN, name + ".pgm"))
-    return gray, doc
+from aruco_amd.fixtures import GOLDEN, load_case, read_pgm  # noqa: F401  (re-exported for the tests)
 
 
 def rel_err(a, b):
