@@ -471,6 +471,9 @@ __device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lan
     return tb_assemble_mirror((r[0] >> sh) & 7u, (r[LANES] >> sh) & 7u, (r[2 * LANES] >> sh) & 7u);
 }
 
+#ifndef PER_LANE_RELOAD
+#define PER_LANE_RELOAD 1
+#endif
 constexpr int CHUNK = 8;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length)
 
 // Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
@@ -497,7 +500,8 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
             const int lx = x - blk.bx, ly = y - blk.by;
             const bool near = (lx < 1 + CHUNK && blk.bx > 0) || (lx > 30 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
                               (ly > 30 - CHUNK && blk.by < maxby);
-            if (__any(walking && near)) tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+            static_assert(true, "");
+            if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
         }
         const uint32_t* rb = rows + lane - (blk.by + 1) * LANES;   // row y of the image sits at rb[y * LANES]
         const int xo = -blk.bx - 1;
