@@ -20,6 +20,34 @@ namespace ah {
 void launch_rotate_x(hipStream_t s, double* rt);
 }
 
+namespace ah {
+Tuning read_tuning() {
+    Tuning t;
+    auto geti = [](const char* name, int dflt) {
+        const char* e = getenv(name);
+        return (e && *e) ? atoi(e) : dflt;
+    };
+    t.walk_fork = geti("ARUCOHIP_WALK_FORK", 1) != 0;
+    t.chain = geti("ARUCOHIP_CHAIN", 0) != 0;
+    t.cand_sparse = geti("ARUCOHIP_CAND_SPARSE", 1) != 0;
+    t.cand_waves = std::max(1, geti("ARUCOHIP_CAND_WAVES", 32));
+    t.cand_chunks = std::max(1, geti("ARUCOHIP_CAND_CHUNKS", 16));
+    t.leash = geti("ARUCOHIP_LEASH", 0);
+    t.fork_after = geti("ARUCOHIP_FORK_AFTER", 7);
+    t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
+    t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
+    if (const char* e = getenv("ARUCOHIP_GENS")) {
+        for (const char* q = e; *q && t.ngens < 32;) {
+            const int v = atoi(q);
+            if (v > 0) t.gens[t.ngens++] = v;
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
+    return t;
+}
+}  // namespace ah
+
 using namespace ah;
 
 enum { STAGE_THRESHOLD = 0, STAGE_RECTANGLES, STAGE_IDENTIFY, STAGE_SUBPIXEL, STAGE_FILTERING, STAGE_COUNT };
@@ -267,6 +295,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     }
     const size_t F = h->cap_frames, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
+    b.tune = read_tuning();
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
     b.long_cap = (uint32_t)std::min(std::max(lim->long_walks_per_plane, 64), 1 << 16);
@@ -601,8 +630,7 @@ static int user_decode_stage(arucohip_handle* h, const DetectParams& dp) {
 }
 
 static void run_walkers_and_quads(arucohip_handle* h, hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& dp) {
-    static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
-    WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, nullptr};
+    WalkFork fk{h->buf.tune.walk_fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, nullptr};
     const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, h->buf);
     launch_contour_quads(s, g, nframes, dp, h->buf, forked ? 1 : 0);
     if (forked) {
@@ -666,8 +694,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         launch_start_candidates(s, g, nframes * dp.nthr, b);
         MARK(K_WALKERS);
         // walkers; their late generations run on the side stream under the first quad pass (the contour_quad mark sits at the fork)
-        static const bool fork = !(getenv("ARUCOHIP_WALK_FORK") && atoi(getenv("ARUCOHIP_WALK_FORK")) == 0);
-        WalkFork fk{fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};
+        WalkFork fk{b.tune.walk_fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};
         const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, b);
         MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
@@ -855,7 +882,7 @@ static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nfra
         // optional stagger (ARUCOHIP_CHAIN=1): the bandwidth-bound threshold kernels of the chunks run one after the other,
         // so that chunk c's threshold overlaps the latency-bound border following / decoding of chunk c-1. Helps with 4
         // streams on some boxes and hurts on others, hence off by default.
-        static const bool chain = getenv("ARUCOHIP_CHAIN") && atoi(getenv("ARUCOHIP_CHAIN")) != 0;
+        const bool chain = h->buf.tune.chain != 0;
         w->wait_thr = (chain && c > 0) ? (c == 1 ? h : h->kids[c - 2])->ev_thr : nullptr;
         rc = chunk_enqueue(w, frames + (size_t)off * frame_stride, cnt, W, H, row_stride, frame_stride, frames_on_device, channels, dp, cam,
                            out ? out + (size_t)off * cap : nullptr, cap, n_out + off, out_on_device);

@@ -105,8 +105,27 @@ struct DetectParams {
     const uint64_t* hrm_codes;      // device
 };
 
+// Tuning / A-B knobs. They are environment variables (INTEGRATION.md lists them), read ONCE when a handle is created and
+// kept with it: a handle behaves the same for its whole life whatever the environment does later, and no kernel launcher
+// touches the environment.
+struct Tuning {
+    int walk_fork = 1;         // ARUCOHIP_WALK_FORK: late walker generations on a side stream
+    int chain = 0;             // ARUCOHIP_CHAIN: threshold kernels of chunk streams one after the other
+    int cand_sparse = 1;       // ARUCOHIP_CAND_SPARSE: bitmap-driven start candidates
+    int cand_waves = 32;       // ARUCOHIP_CAND_WAVES: waves per plane of that kernel (4 0.25, 8 0.18, 16 0.13, 32 0.13 ms per 512 frames)
+    int cand_chunks = 16;      // ARUCOHIP_CAND_CHUNKS: workgroups per plane of the lane-per-tile kernel
+    int leash = 0;             // ARUCOHIP_LEASH: steps of the first walker pass (0 = default)
+    int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
+    int ngens = 0;
+    int fork_after = 7;        // ARUCOHIP_FORK_AFTER: generations on the main stream
+    int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
+    int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
+};
+Tuning read_tuning();          // capi.hip
+
 // device pointers + capacities handed to kernels
 struct Buffers {
+    Tuning tune;
     uint8_t* thres;
     uint64_t* tiles;       // [P][tiles_y(H)][tiles_x(W)] binary image in 8x8-pixel tiles (bits_tiles.h)
     uint64_t* tile_bits;   // [P][tiles_y(H)][2 * tile_strips(W)] non-empty-tile bitmap: per 128-tile strip one word for the even

@@ -372,13 +372,12 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
 }
 
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
-    static const bool sparse_ok = !(getenv("ARUCOHIP_CAND_SPARSE") && atoi(getenv("ARUCOHIP_CAND_SPARSE")) == 0);   // A-B knob
-    if (!b.seg_mode && sparse_ok) {
+    if (!b.seg_mode && b.tune.cand_sparse) {
         SparseArgs a;
         a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.nstrips = tile_strips(g.width);
         a.width = g.width, a.height = g.height, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
         const int nty = a.tny - 1;
-        const int waves = getenv("ARUCOHIP_CAND_WAVES") ? std::max(1, atoi(getenv("ARUCOHIP_CAND_WAVES"))) : 32;   // waves per plane (tuning knob: 4 0.25, 8 0.18, 16 0.13, 32 0.13 ms per 512 frames)
+        const int waves = b.tune.cand_waves;
         hipLaunchKernelGGL(candidates_sparse_kernel, dim3(std::min(waves, nty), nplanes), dim3(64), 0, s, a);
         return;
     }
@@ -389,7 +388,7 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
     a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig;
     a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
     const int ntiles = (a.tnx - 1) * (a.tny - 1);
-    const int maxchunks = getenv("ARUCOHIP_CAND_CHUNKS") ? std::max(1, atoi(getenv("ARUCOHIP_CAND_CHUNKS"))) : 16;   // tuning knob
+    const int maxchunks = b.tune.cand_chunks;
     const int chunks = std::max(1, std::min(maxchunks, (ntiles + 4 * CAND_THREADS - 1) / (4 * CAND_THREADS)));
     hipLaunchKernelGGL(candidates_kernel, dim3(chunks, nplanes), dim3(CAND_THREADS), 0, s, a);
 }
@@ -741,8 +740,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     a.gen_ring = (uint32_t*)(a.gen_state + 4 * (size_t)a.gen_cap);
     a.gen = 0, a.gen_steps = 0;
     {
-        const char* e = getenv("ARUCOHIP_LEASH");
-        const int v = e ? atoi(e) : LEASH_DEFAULT;
+        const int v = b.tune.leash > 0 ? b.tune.leash : LEASH_DEFAULT;
         a.leash = (v >= CK && v <= LEASH_MAX && v % CK == 0) ? v : LEASH_DEFAULT;
     }
     const int planes8 = ((nplanes + 7) / 8) * 8;
@@ -756,20 +754,15 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     // schedule: ARUCOHIP_GENS="64,64,128,..." overrides for tuning; after the listed generations the length stays 1024
     int kSteps[GEN_MAX], nsched = 0;
     {
-        const char* e = getenv("ARUCOHIP_GENS");
-        static const int kDefault[] = {64, 64, 64, 128, 128, 256, 256, 512, 512};   // fork after 7: borders up to 1024 points are in pass 1
-        if (e && *e) {
-            for (const char* q = e; *q && nsched < GEN_MAX;) {
-                const int v = atoi(q);
-                if (v >= CHUNK && v % CHUNK == 0 && v % CK == 0) kSteps[nsched++] = v;
-                while (*q && *q != ',') q++;
-                if (*q == ',') q++;
-            }
+        for (int i = 0; i < b.tune.ngens && nsched < GEN_MAX; i++) {   // ARUCOHIP_GENS="64,64,128,..."; after the listed generations the length stays 1024
+            const int v = b.tune.gens[i];
+            if (v >= CHUNK && v % CHUNK == 0 && v % CK == 0) kSteps[nsched++] = v;
         }
+        static const int kDefault[] = {64, 64, 64, 128, 128, 256, 256, 512, 512};   // fork after 7: borders up to 1024 points are in pass 1
         if (nsched == 0)
             for (int v : kDefault) kSteps[nsched++] = v;
     }
-    const int kForkAfter = getenv("ARUCOHIP_FORK_AFTER") ? atoi(getenv("ARUCOHIP_FORK_AFTER")) : 7;   // tuning knob
+    const int kForkAfter = b.tune.fork_after;
     int done = a.leash;
     bool forked = false;
     hipStream_t cur = s;
@@ -1072,7 +1065,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    const int qb = getenv("ARUCOHIP_QUAD_BLOCKS") ? std::max(1, atoi(getenv("ARUCOHIP_QUAD_BLOCKS"))) : 24;   // workgroups per plane (tuning knob; 8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
+    const int qb = b.tune.quad_blocks;
     hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? std::max(1, qb / 2) : qb, nframes * p.nthr), dim3(64), 0, s, a);
 }
 

@@ -37,6 +37,7 @@ struct ThrArgs {
     int tnx, tny;         // tiles per row / column of the tiled binary image
     int fast;             // width, strides and base address are multiples of 4: dword loads and stores (template FAST)
     int fast16;           // ... multiples of 16 and width >= 16: the 16-pixel-per-lane kernel applies
+    int wide_ok;          // Tuning::threshold_wide
     uint8_t* thres;
     uint64_t* tiles;
     uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
@@ -460,9 +461,8 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
     dim3 grid((a.width + STRIP - 1) / STRIP, (a.height + SEG - 1) / SEG, nframes);
     constexpr bool CAN16 = R <= 5;
     const long lim = (long)(256 + abs(a.idelta)) * a.n + a.n_half;
-    static const bool wide_ok = !(getenv("ARUCOHIP_THRESHOLD_WIDE") && atoi(getenv("ARUCOHIP_THRESHOLD_WIDE")) == 0);   // tuning / A-B knob
     if constexpr (R <= 4) {
-        if (a.fast16 && lim < 32768 && wide_ok) {
+        if (a.fast16 && lim < 32768 && a.wide_ok) {
             // prefetch depth 3 rows, 128-row segments: the best of the sweep (PF 2..5, segments 64 / 128 / 256, forced register
             // budgets; profiles/r02_threshold_sweep.txt: 0.53 ms per 512 frames, everything else 0.54 .. 1.6)
             dim3 wgrid0((a.width + WSTRIP - 1) / WSTRIP, (a.height + 127) / 128, nframes);
@@ -483,7 +483,7 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
     a.width = g.width, a.height = g.height, a.nthr = nthr, a.t = t;
     a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
-    a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width);
+    a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width), a.wide_ok = b.tune.threshold_wide;
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.fast = ((g.width | (int)(g.row_stride & 3) | (int)(g.frame_stride & 3) | (int)((uintptr_t)gray & 3)) & 3) == 0;
     a.fast16 = g.width >= 16 && ((g.width | (int)(g.row_stride & 15) | (int)(g.frame_stride & 15) | (int)((uintptr_t)gray & 15) | (int)((uintptr_t)b.thres & 15)) & 15) == 0;
