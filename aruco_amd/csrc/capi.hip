@@ -75,6 +75,8 @@ struct arucohip_handle {
     size_t bgr_bytes = 0;
     uint8_t* d_erode = nullptr;       // eroded planes (params.erode)
     size_t erode_bytes = 0;
+    uint8_t* d_canny = nullptr;       // CANNY: survivor tiles, edge tiles, changed flag
+    size_t canny_bytes = 0;
     // frame undistortion (arucohip_undistort): the map of the last camera is kept
     short2* d_umap_xy = nullptr;
     uint16_t* d_umap_f = nullptr;
@@ -209,8 +211,7 @@ static int validate_params(arucohip_handle* h, const arucohip_params_t* p) {
         return fail(h, ARUCOHIP_E_INVALID, "setMinMaxSize: need 0 < min < max <= 1");
     if (p->warp_size < 10) return fail(h, ARUCOHIP_E_INVALID, "setWarpSize: need >= 10");
     if (p->warp_size > 128) return fail(h, ARUCOHIP_E_UNSUPPORTED, "warp size > 128 not supported");
-    if (p->thres_method == ARUCOHIP_THRES_CANNY) return fail(h, ARUCOHIP_E_UNSUPPORTED, "CANNY threshold is not on the accelerated path");
-    if (p->thres_method != ARUCOHIP_THRES_FIXED && p->thres_method != ARUCOHIP_THRES_ADPT) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
+    if (p->thres_method < ARUCOHIP_THRES_FIXED || p->thres_method > ARUCOHIP_THRES_CANNY) return fail(h, ARUCOHIP_E_INVALID, "bad threshold method");
     if (p->corner_method < ARUCOHIP_CORNER_NONE || p->corner_method > ARUCOHIP_CORNER_LINES) return fail(h, ARUCOHIP_E_INVALID, "bad corner method");
     if (p->use_locked_corners && (p->corner_method == ARUCOHIP_CORNER_HARRIS || p->corner_method == ARUCOHIP_CORNER_SUBPIX) &&
         ((int)p->thres_param1 < 1 || (int)p->thres_param1 > 31))
@@ -239,7 +240,7 @@ static void free_all(arucohip_handle* h) {
         if (e) hipEventDestroy(e);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
+    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -655,6 +656,26 @@ static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, 
 
 static int grow(arucohip_handle* h, uint8_t** buf, size_t* have, size_t need);
 
+// threshold stage of any method into buf.thres / buf.tiles (+ bitmap). CANNY (markerdetector.cpp:667-676) blocks the host while its
+// hysteresis converges.
+static int run_threshold(arucohip_handle* h, hipStream_t s, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp) {
+    const Buffers& b = h->buf;
+    if (dp.thres_method != ARUCOHIP_THRES_CANNY) {
+        launch_threshold(s, gray_dev, g, nframes, dp, b);
+        return ARUCOHIP_OK;
+    }
+    const size_t ntiles = (size_t)nframes * dp.nthr * ((g.width + 7) / 8) * ((g.height + 7) / 8);
+    int rc = grow(h, &h->d_canny, &h->canny_bytes, 2 * ntiles * sizeof(uint64_t) + 64);
+    if (rc) return rc;
+    uint64_t* surv = (uint64_t*)h->d_canny;
+    uint64_t* edge = surv + ntiles;
+    if (launch_canny(s, gray_dev, g, nframes, dp.nthr, b, surv, edge, (uint32_t*)(edge + ntiles))) return fail(h, ARUCOHIP_E_HIP, "CANNY kernels failed");
+    FrameGeom tg = g;
+    tg.row_stride = (size_t)g.width, tg.frame_stride = (size_t)g.width * g.height;
+    launch_binary_planes(s, b.thres, tg, nframes * dp.nthr, b);   // contour tiles + bitmap from the edge image
+    return ARUCOHIP_OK;
+}
+
 static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp, const CamModel& cam) {
     hipStream_t s = h->stream;
     Buffers& b = h->buf;
@@ -674,7 +695,10 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
     MARK(K_THRESHOLD);
     if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));
-    launch_threshold(s, gray_dev, g, nframes, dp, b);
+    {
+        const int rc_ = run_threshold(h, s, gray_dev, g, nframes, dp);
+        if (rc_) return rc_;
+    }
     if (h->params.erode) {
         int rc_ = grow(h, &h->d_erode, &h->erode_bytes, (size_t)nframes * dp.nthr * g.width * g.height);
         if (rc_) return rc_;
@@ -1229,7 +1253,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     HIPCHK(h, hipMemsetAsync(h->buf.ring_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
-    launch_threshold(h->stream, gray_dev, g, 1, dp, h->buf);
+    if ((rc = run_threshold(h, h->stream, gray_dev, g, 1, dp))) return rc;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -176,6 +176,7 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
 void launch_undist_map(hipStream_t s, int W, int H, const float* K, const float* dist, int ndist, short2* xy, uint16_t* fxy);
 void launch_remap(hipStream_t s, const uint8_t* src, size_t row_stride, size_t frame_stride, int W, int H, int cn, int nframes, const short2* xy,
                   const uint16_t* fxy, uint8_t* dst);
+int launch_canny(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, int nthr, const Buffers& b, uint64_t* surv, uint64_t* edge, uint32_t* changed);
 void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);
 void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);

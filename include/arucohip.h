@@ -28,7 +28,8 @@ enum {
     ARUCOHIP_OK = 0,
     ARUCOHIP_E_INVALID = 1,      /* bad argument: what the reference rejects with CV_Assert (markerdetector.cpp:644,685,1032-1034,1048) */
     ARUCOHIP_E_CAPACITY = 2,     /* output array too small; *n_out holds the required count */
-    ARUCOHIP_E_UNSUPPORTED = 3,  /* a parameter value outside what the device kernels are built for (e.g. warp size > 128) */
+    ARUCOHIP_E_UNSUPPORTED = 3,  /* a parameter value outside what the device kernels are built for (warp size > 128, adaptive block > 31,
+                                    SUBPIX window > 15, locked-corner window > 31, dictionary markers beyond 8x8 / 4096 entries) */
     ARUCOHIP_E_HIP = 4,          /* HIP runtime failure, see arucohip_last_error_string */
     ARUCOHIP_E_OVERFLOW = 5,     /* an internal device list overflowed (raise limits with arucohip_create_ex) */
     ARUCOHIP_E_BOARD_CONFIG = 6  /* empty board configuration (boarddetector.cpp:93) */

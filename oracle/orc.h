@@ -29,7 +29,7 @@ struct Contour {
 
 // Mirrors the private members of aruco::MarkerDetector (src/markerdetector.cpp:235-249 defaults).
 struct Params {
-    int thres_method = 1;       // 0 FIXED_THRES, 1 ADPT_THRES, 2 CANNY (unsupported)
+    int thres_method = 1;       // 0 FIXED_THRES, 1 ADPT_THRES, 2 CANNY
     double thres_p1 = 7, thres_p2 = 7;
     int thres_range = 0;        // _thresParam1_range
     int corner_method = 3;      // 0 NONE, 1 HARRIS, 2 SUBPIX, 3 LINES
@@ -127,6 +127,7 @@ void refine_lines(Candidate& cand, const float* K, const float* dist, int ndist)
 void corner_subpix(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n, int win, int max_iter, double eps);
 void corner_harris_refine(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n);
 // orc_extra.cpp
+void canny_3x3_l1(const uint8_t* src, int w, int h, int stride, int low, int high, uint8_t* dst);
 void undistort_8u(const uint8_t* src, int w, int h, size_t stride, int cn, const float K[9], const float* dist, int ndist, uint8_t* dst);
 void find_corner_maxima(const uint8_t* gray, int w, int h, int stride, Pt2f* corners, int n, int wsize);
 void corner_harris_window(const uint8_t* gray, int w, int h, int stride, int x0, int y0, int x1, int y1, std::vector<float>& harr);

@@ -267,6 +267,15 @@ def undistort(img, K, dist):
     return out
 
 
+def canny(gray, low=10, high=220):
+    """cv::Canny(gray, out, low, high) with the 3x3 Sobel and the L1 magnitude."""
+    g, gp = _u8(gray)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_canny(gp, w, h, w, int(low), int(high), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def find_corner_maxima(gray, pts, wsize):
     g, gp = _u8(gray)
     h, w = g.shape

@@ -181,6 +181,7 @@ void orc_corner_harris(const uint8_t* gray, int w, int h, int stride, float* xy,
 void orc_undistort(const uint8_t* src, int w, int h, int stride, int cn, const float* K, const float* dist, int ndist, uint8_t* dst) {
     undistort_8u(src, w, h, (size_t)stride, cn, K, dist, ndist, dst);
 }
+void orc_canny(const uint8_t* src, int w, int h, int stride, int low, int high, uint8_t* dst) { canny_3x3_l1(src, w, h, stride, low, high, dst); }
 void orc_find_corner_maxima(const uint8_t* gray, int w, int h, int stride, float* xy, int n, int wsize) {
     find_corner_maxima(gray, w, h, stride, (Pt2f*)xy, n, wsize);
 }

@@ -398,13 +398,15 @@ int Detector::detect(const uint8_t* gray, int W, int H, int stride, const float*
                      float marker_size, int y_perp, std::vector<Marker>& out) {
     out.clear();
     w = W, h = H;
-    if (prm.thres_method == 2) return -2;  // CANNY: not restated
+
     // thresholds :322-334
     const int nthr = 2 * prm.thres_range + 1;
     std::vector<std::vector<uint8_t>> thr(nthr, std::vector<uint8_t>((size_t)W * H));
     for (int i = 0; i < nthr; i++) {
         double p1 = nthr == 1 ? prm.thres_p1 : prm.thres_p1 - prm.thres_range + prm.thres_range * i;
-        if (prm.thres_method == 0) {
+        if (prm.thres_method == 2) {
+            canny_3x3_l1(gray, W, H, stride, 10, 220, thr[i].data());   // :667-676, the parameters are not used
+        } else if (prm.thres_method == 0) {
             fixed_threshold_inv(gray, W, H, stride, p1, thr[i].data());
         } else {
             if (p1 < 3)

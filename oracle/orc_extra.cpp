@@ -179,4 +179,72 @@ void find_corner_maxima(const uint8_t* gray, int w, int h, int stride, Pt2f* cor
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cv::Canny(grey, out, 10, 220) — the CANNY threshold method (/root/reference/src/markerdetector.cpp:667-676): aperture 3, L1
+// gradient magnitude. OpenCV 3.0 imgproc/src/canny.cpp: Sobel dx, dy (CV_16S, BORDER_REPLICATE), mag = |dx| + |dy| with a
+// zero rim around the image, non-maximum suppression along the quantised gradient direction (tan 22.5 deg in 15-bit fixed
+// point; the asymmetric > / >= comparisons), then hysteresis: every suppression survivor (mag > low) that is 8-connected
+// to a survivor with mag > high is an edge. (The scan's `prev_flag` / "pixel above already an edge" shortcuts only skip
+// seeds that a neighbouring seed reaches anyway, so the edge set is this connectivity closure.) The reference holds no
+// fixture for this method: PARITY UNPINNED at the OpenCV level.
+// ---------------------------------------------------------------------------------------------
+void canny_3x3_l1(const uint8_t* src, int w, int h, int stride, int low, int high, uint8_t* dst) {
+    auto G = [&](int x, int y) -> int { return src[(size_t)std::min(std::max(y, 0), h - 1) * stride + std::min(std::max(x, 0), w - 1)]; };
+    std::vector<int> dx((size_t)w * h), dy((size_t)w * h), mag((size_t)(w + 2) * (h + 2), 0);
+    const int ms = w + 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int gx = (G(x + 1, y - 1) + 2 * G(x + 1, y) + G(x + 1, y + 1)) - (G(x - 1, y - 1) + 2 * G(x - 1, y) + G(x - 1, y + 1));
+            const int gy = (G(x - 1, y + 1) + 2 * G(x, y + 1) + G(x + 1, y + 1)) - (G(x - 1, y - 1) + 2 * G(x, y - 1) + G(x + 1, y - 1));
+            dx[(size_t)y * w + x] = gx, dy[(size_t)y * w + x] = gy;
+            mag[(size_t)(y + 1) * ms + x + 1] = std::abs(gx) + std::abs(gy);
+        }
+    const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
+    std::vector<uint8_t> state((size_t)w * h, 0);   // 0 suppressed, 1 survivor, 2 edge
+    std::vector<int> stack;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int* m = &mag[(size_t)(y + 1) * ms + x + 1];
+            const int v = m[0];
+            bool keep = false;
+            if (v > low) {
+                const int xs = dx[(size_t)y * w + x], ys = dy[(size_t)y * w + x];
+                const int ax = std::abs(xs);
+                const int ay = std::abs(ys) << 15;
+                const int tg22x = ax * TG22;
+                if (ay < tg22x) {
+                    keep = v > m[-1] && v >= m[1];
+                } else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x)
+                        keep = v > m[-ms] && v >= m[ms];
+                    else {
+                        const int s = (xs ^ ys) < 0 ? -1 : 1;
+                        keep = v > m[-ms - s] && v > m[ms + s];
+                    }
+                }
+            }
+            if (keep) {
+                state[(size_t)y * w + x] = 1;
+                if (v > high) {
+                    state[(size_t)y * w + x] = 2;
+                    stack.push_back(y * w + x);
+                }
+            }
+        }
+    while (!stack.empty()) {
+        const int p = stack.back();
+        stack.pop_back();
+        const int px = p % w, py = p / w;
+        for (int oy = -1; oy <= 1; oy++)
+            for (int ox = -1; ox <= 1; ox++) {
+                const int qx = px + ox, qy = py + oy;
+                if (qx < 0 || qx >= w || qy < 0 || qy >= h) continue;
+                uint8_t& st = state[(size_t)qy * w + qx];
+                if (st == 1) st = 2, stack.push_back(qy * w + qx);
+            }
+    }
+    for (size_t i = 0; i < (size_t)w * h; i++) dst[i] = state[i] == 2 ? 255 : 0;
+}
+
 }  // namespace orc

@@ -256,10 +256,15 @@ def test_error_codes(env, handle):
     with pytest.raises(capi.ArucoHipError):
         handle.set_params(p)
     p = handle.get_params()
-    p.thres_method = capi.THRES_CANNY
+    p.warp_size = 200                       # a value the device kernels are not built for (patches up to 128x128)
     with pytest.raises(capi.ArucoHipError) as e:
         handle.set_params(p)
     assert e.value.code == capi.E_UNSUPPORTED
+    p = handle.get_params()
+    p.thres_method = 7                      # not a ThresholdMethods value
+    with pytest.raises(capi.ArucoHipError) as e:
+        handle.set_params(p)
+    assert e.value.code == capi.E_INVALID
     g, _ = load_case("board")
     with pytest.raises(capi.ArucoHipError) as e:
         handle.detect(g, cap=3)

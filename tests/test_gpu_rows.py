@@ -142,3 +142,42 @@ def test_locked_corners(env):
                     assert moved > 0.01
             finally:
                 h.close()
+
+
+def test_canny_threshold_method(env):
+    """Row a2's CANNY alternative (reference src/markerdetector.cpp:667-676: cv::Canny(grey, out, 10, 220)): the edge image of
+    the device (suppression tiles + block-wise hysteresis to the fixed point) equals the restatement byte for byte on
+    fixtures, noise, a frame that is not a multiple of 8 and a 1080p frame; detection with the method equals the oracle's."""
+    capi, orc = env["capi"], env["orc"]
+    rng = np.random.RandomState(21)
+    fr, _ = env["synth"].make_stream(1, width=1920, height=1080, seed=5, device="cuda")
+    base = ndimage_like_blur(rng.rand(203, 331))
+    cases = [("single", load_case("single")[0]), ("board", load_case("board")[0]), ("smooth_331x203", (base * 255).astype(np.uint8)),
+             ("noise_64x48", rng.randint(0, 256, (48, 64)).astype(np.uint8)), ("synth1080", fr[0].cpu().numpy())]
+    h = capi.Handle(1920, 1080, max_batch=1)
+    try:
+        for name, g in cases:
+            got = h.threshold(g, capi.THRES_CANNY)
+            exp = orc.canny(g)
+            assert np.array_equal(got, exp), (name, int((got != exp).sum()))
+            assert 0 < exp.mean() < 128
+        p = h.get_params()
+        p.thres_method = capi.THRES_CANNY
+        h.set_params(p)
+        for name in ("single", "board"):
+            g = load_case(name)[0]
+            got = h.detect(g)
+            ref = orc.Oracle(thres_method=2).detect(g)
+            assert [int(m["id"]) for m in got] == [m["id"] for m in ref] and len(got) >= 5, name
+            for a, b in zip(got, ref):
+                ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+                assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4
+            assert np.array_equal(h.thresholded(0, g.shape), orc.canny(g))
+    finally:
+        h.close()
+
+
+def ndimage_like_blur(a):
+    for _ in range(6):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5
+    return (a - a.min()) / (a.max() - a.min())

@@ -275,3 +275,32 @@ def test_corner_harris_window_and_maxima_against_scipy():
         by, bx = np.unravel_index(np.argmax(score), score.shape)
         out = orc.find_corner_maxima(img, [[px, py]], ws)[0]
         assert (out[0], out[1]) == (bx + x0, by + y0), (out, bx + x0, by + y0)
+
+
+def test_canny_against_numpy_and_connected_components():
+    """CANNY method: Sobel by scipy correlation with replicated borders, vectorised non-maximum suppression on the quantised
+    direction, hysteresis as "survivor components (8-connectivity, scipy.ndimage.label) that contain a seed" — exact."""
+    rng = np.random.RandomState(10)
+    for g in (load_case("single")[0], _smooth_noise(rng, 120, 173, 2.0), rng.randint(0, 256, (40, 56)).astype(np.uint8)):
+        f = g.astype(np.int64)
+        dx = ndimage.correlate(f, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]), mode="nearest")
+        dy = ndimage.correlate(f, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]]), mode="nearest")
+        mag = np.abs(dx) + np.abs(dy)
+        mp = np.pad(mag, 1)
+        c = mp[1:-1, 1:-1]
+        ax, ay = np.abs(dx), np.abs(dy) << 15
+        tg22 = ax * 13573
+        tg67 = tg22 + (ax << 16)
+        horiz = ay < tg22
+        vert = ~horiz & (ay > tg67)
+        diag = ~horiz & ~vert
+        s = np.where((dx ^ dy) < 0, -1, 1)
+        yy, xx = np.mgrid[0:g.shape[0], 0:g.shape[1]]
+        keep_h = (c > mp[1:-1, :-2]) & (c >= mp[1:-1, 2:])
+        keep_v = (c > mp[:-2, 1:-1]) & (c >= mp[2:, 1:-1])
+        keep_d = (c > mp[yy, xx + 1 - s]) & (c > mp[yy + 2, xx + 1 + s])
+        surv = (c > 10) & ((horiz & keep_h) | (vert & keep_v) | (diag & keep_d))
+        lab, n = ndimage.label(surv, structure=np.ones((3, 3)))
+        seeds = np.unique(lab[surv & (c > 220)])
+        exp = np.where(np.isin(lab, seeds[seeds > 0]), 255, 0).astype(np.uint8)
+        assert np.array_equal(orc.canny(g), exp)
