@@ -33,7 +33,7 @@ Tuning read_tuning() {
     t.cand_waves = std::max(1, geti("ARUCOHIP_CAND_WAVES", 32));
     t.cand_chunks = std::max(1, geti("ARUCOHIP_CAND_CHUNKS", 16));
     t.leash = geti("ARUCOHIP_LEASH", 0);
-    t.fork_after = geti("ARUCOHIP_FORK_AFTER", 7);
+    t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     if (const char* e = getenv("ARUCOHIP_GENS")) {

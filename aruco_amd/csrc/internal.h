@@ -117,7 +117,7 @@ struct Tuning {
     int leash = 0;             // ARUCOHIP_LEASH: steps of the first walker pass (0 = default)
     int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
     int ngens = 0;
-    int fork_after = 7;        // ARUCOHIP_FORK_AFTER: generations on the main stream
+    int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
 };

@@ -758,7 +758,9 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
             const int v = b.tune.gens[i];
             if (v >= CHUNK && v % CHUNK == 0 && v % CK == 0) kSteps[nsched++] = v;
         }
-        static const int kDefault[] = {64, 64, 64, 128, 128, 256, 256, 512, 512};   // fork after 7: borders up to 1024 points are in pass 1
+        // round 2 (every lane re-centres its own block): few long generations beat many short ones; the side stream takes over
+        // after 128 + 256 + 512 steps, borders of up to 960 points are in contour_quad's first pass (profiles/r02_walker_experiments.txt)
+        static const int kDefault[] = {128, 256, 512, 1024};
         if (nsched == 0)
             for (int v : kDefault) kSteps[nsched++] = v;
     }
@@ -779,7 +781,8 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
         done += a.gen_steps;
         // enough workgroups that every wave-load of walks runs at once while many walks are alive (about a fifth of a
         // plane's ~1000 candidates reach generation 1), fewer for the thin late generations; surplus workgroups exit at once
-        const int per_plane_x16 = g <= 2 ? 64 : g <= 4 ? 40 : g <= 7 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
+        const int before = done - a.gen_steps;   // steps every walk of this generation has behind it
+        const int per_plane_x16 = before < 200 ? 64 : before < 450 ? 40 : before < 1100 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
         a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2));
         hipLaunchKernelGGL(walker_long_kernel, dim3(2 * a.gen_blocks), dim3(64), 0, cur, a);
     }
