@@ -759,7 +759,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
             if (v >= CHUNK && v % CHUNK == 0 && v % CK == 0) kSteps[nsched++] = v;
         }
         // round 2 (every lane re-centres its own block): few long generations beat many short ones; the side stream takes over
-        // after 128 + 256 + 512 steps, borders of up to 960 points are in contour_quad's first pass (profiles/r02_walker_experiments.txt)
+        // after 128 + 256 + 512 steps, borders of up to 960 points are in contour_quad's first pass (profiles/r02_kernel_experiments.txt)
         static const int kDefault[] = {128, 256, 512, 1024};
         if (nsched == 0)
             for (int v : kDefault) kSteps[nsched++] = v;
