@@ -11,6 +11,10 @@ rows = list(csv.reader(open(os.path.join(src, "kernel_stats.csv"))))
 rows = [rows[0]] + [r for r in rows[1:] if "ah::" in r[0]]   # this library's kernels only (torch's frame generator is noise)
 with open(os.path.join("profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
     csv.writer(f).writerows(rows)
+if not os.path.exists(os.path.join(src, "fetch_counters.csv")):   # PASSES=trace: kernel stats only
+    for r in rows[:14]:
+        print(r[0][:60], r[1:4])
+    sys.exit(0)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("fetch_counters.csv", "write_counters.csv"):
     for r in csv.DictReader(open(os.path.join(src, name))):
