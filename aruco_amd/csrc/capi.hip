@@ -107,6 +107,8 @@ struct arucohip_handle {
     int* d_small_i = nullptr;
     uint8_t* d_patch = nullptr;       // MAX_WARP^2
     void* d_board = nullptr;          // batched board results + ids
+    uint32_t* zero_block = nullptr;   // counters, gen_cnt, trig_cnt, raw_cnt, ring_cnt: zeroed together at the start of a batch
+    size_t zero_words = 0;
     double* d_gl = nullptr;           // batched GL modelview matrices
     size_t gl_bytes = 0;
     // last call
@@ -238,9 +240,9 @@ static void free_all(arucohip_handle* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
-    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.raw_cnt), hipFree(h->buf.trig), hipFree(h->buf.trig_cnt), hipFree(h->buf.gen_buf), hipFree(h->buf.ring_cnt), hipFree(h->buf.gen_cnt), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
+    hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.trig), hipFree(h->buf.gen_buf), hipFree(h->zero_block), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
-    hipFree(h->buf.counters), hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
+    hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -316,7 +318,6 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.tile_bits, P * (size_t)tiles_y(lim->max_height) * 2 * tile_strips(lim->max_width) * sizeof(uint64_t));
     h->bits_bytes = bits_bytes;
     ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
-    ALLOC(b.raw_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
     {
         // contour pipeline: ARUCOHIP_CONTOURS = walkers | segments; default by handle shape. The per-candidate walkers win on
@@ -335,10 +336,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.node, P * (size_t)b.cap_raw * sizeof(uint4));
     ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
     ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
-    ALLOC(b.trig_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
     ALLOC(b.gen_buf, P * (size_t)b.long_cap * 4 * 20);   // [2 kinds][2 parities][P * long_cap] walk states (16 B) + ring ids (4 B)
-    ALLOC(b.ring_cnt, P * TRIG_CNT_STRIDE * sizeof(uint32_t));
-    ALLOC(b.gen_cnt, GEN_CNT_WORDS * sizeof(uint32_t));
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));
@@ -352,7 +350,18 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.markers, F * b.cap_markers * sizeof(arucohip_marker_t));
     ALLOC(b.nmarkers, F * sizeof(int32_t));
     ALLOC(b.marker_list, F * (size_t)b.cap_markers * sizeof(uint32_t));
-    ALLOC(b.counters, (CNT_FIXED + F) * sizeof(uint32_t));
+    {
+        // every counter a batch starts from zero with lives in one block: one memset per batch instead of five (a single frame's
+        // call is a chain of ~25 short operations, each memset was 6 us of it)
+        const size_t w_cnt = (CNT_FIXED + F + 31) & ~(size_t)31, w_plane = P * TRIG_CNT_STRIDE;
+        h->zero_words = w_cnt + GEN_CNT_WORDS + 3 * w_plane;
+        ALLOC(h->zero_block, h->zero_words * sizeof(uint32_t));
+        b.counters = h->zero_block;
+        b.gen_cnt = b.counters + w_cnt;
+        b.trig_cnt = b.gen_cnt + GEN_CNT_WORDS;
+        b.raw_cnt = b.trig_cnt + w_plane;
+        b.ring_cnt = b.raw_cnt + w_plane;
+    }
     ALLOC(h->d_small_f, 8192 * sizeof(float));
     ALLOC(h->d_small_d, 64 * sizeof(double));
     ALLOC(h->d_small_i, 64 * sizeof(int));
@@ -685,11 +694,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         if ((rc_ = ensure_bits_geometry(h, g.width, g.height))) return rc_;
         if ((rc_ = ensure_patches(h, dp))) return rc_;
     }
-    HIPCHK(h, hipMemsetAsync(b.counters, 0, (CNT_FIXED + nframes) * sizeof(uint32_t), s));
-    HIPCHK(h, hipMemsetAsync(b.trig_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
-    HIPCHK(h, hipMemsetAsync(b.raw_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
-    HIPCHK(h, hipMemsetAsync(b.ring_cnt, 0, (size_t)nframes * dp.nthr * TRIG_CNT_STRIDE * sizeof(uint32_t), s));
-    HIPCHK(h, hipMemsetAsync(b.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), s));
+    HIPCHK(h, hipMemsetAsync(h->zero_block, 0, h->zero_words * sizeof(uint32_t), s));
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
@@ -1247,11 +1252,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     const uint8_t* gray_dev;
     FrameGeom g;
     if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &gray_dev, &g))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.ring_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->zero_block, 0, h->zero_words * sizeof(uint32_t), h->stream));
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     if ((rc = run_threshold(h, h->stream, gray_dev, g, 1, dp))) return rc;
     HIPCHK(h, hipGetLastError());
@@ -1275,11 +1276,7 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int W, 
     const uint8_t* dev;
     FrameGeom g;
     if ((rc = stage_frames(h, thres, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &dev, &g))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->buf.counters, 0, (CNT_FIXED + 1) * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.trig_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.raw_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.ring_cnt, 0, TRIG_CNT_STRIDE * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf.gen_cnt, 0, GEN_CNT_WORDS * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->zero_block, 0, h->zero_words * sizeof(uint32_t), h->stream));
     if ((rc = ensure_walk_scratch(h, 1, dp))) return rc;
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
     launch_binary_planes(h->stream, dev, g, 1, h->buf);

@@ -465,8 +465,18 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
         if (a.fast16 && lim < 32768 && a.wide_ok) {
             // prefetch depth 3 rows, 128-row segments: the best of the sweep (PF 2..5, segments 64 / 128 / 256, forced register
             // budgets; profiles/r02_threshold_sweep.txt: 0.53 ms per 512 frames, everything else 0.54 .. 1.6)
-            dim3 wgrid0((a.width + WSTRIP - 1) / WSTRIP, (a.height + 127) / 128, nframes);
-            hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), wgrid0, dim3(64), 0, s, a);
+            // A wave walks down its segment row by row: a launch of few frames gets shorter segments so that it still spreads over
+            // the chip (one 640x480 frame: 4 waves of 128 rows took 91 us; 2R extra rows per segment are re-read, which only small
+            // launches can afford)
+            const int strips = (a.width + WSTRIP - 1) / WSTRIP;
+            const long waves128 = (long)strips * ((a.height + 127) / 128) * nframes;
+            if (waves128 >= 512) {
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), dim3(strips, (a.height + 127) / 128, nframes), dim3(64), 0, s, a);
+            } else if (waves128 * 4 >= 512) {
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 32>), dim3(strips, (a.height + 31) / 32, nframes), dim3(64), 0, s, a);
+            } else {
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 16>), dim3(strips, (a.height + 15) / 16, nframes), dim3(64), 0, s, a);
+            }
             return true;
         }
     }
