@@ -212,12 +212,13 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
 }
 
 // 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram.
-// Lane = patch column (ws <= 64; wider patches take the columns in turns), the wave walks down the rows: the column
-// terms iM[0]*x, iM[3]*x, iM[6]*x are formed once per lane and the row terms once per row, exactly the products and sums
-// cv::warpPerspective forms; four rows are in flight so that the gathers overlap.
-// Histogram of a patch: a marker patch is two-valued, so most lanes of a row hit one of two bins and LDS atomics on one
+// The wave takes the patch in 8x8-pixel blocks, lane = pixel of the block, four blocks in flight so that the gathers
+// overlap (round 1 mapped lanes to the 56 pixels of a patch row: for a rotated marker every lane then reads a different
+// image row; round 2: 0.75 -> 0.56 ms per 1024 frames). Every pixel forms exactly the products and sums cv::warpPerspective
+// forms (iM[0]*x + (iM[1]*y + iM[2]) ...).
+// Histogram of a patch: a marker patch is two-valued, so most lanes hit one of two bins and LDS atomics on one
 // histogram serialise 50-fold. 32 private copies (one per lane pair) with byte counters packed four to a word cost the same
-// 8 KB as 8 word-sized copies: a copy sees at most 2 * ws <= 128 pixels when ws <= 64, so a byte never
+// 8 KB as 8 word-sized copies: a copy sees at most 2 * (ws / 8)^2 <= 128 pixels when ws <= 64, so a byte never
 // overflows into its neighbour; wider patches use word counters in 8 copies.
 constexpr int HCOPIES = 32, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+3) + 1 so that copies start in different banks
 constexpr int HWCOPIES = 8, HWPITCH = 257;
@@ -241,45 +242,50 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         uint8_t* patch = a.patches + (size_t)idx * npx;
         uint32_t* myhist = bytes ? hist + (lane >> 1) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
         const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
-        for (int x = lane; x < ws; x += WAVE) {
-            const double ax = m0 * x, bx = m3 * x, cx = m6 * x;
-            for (int y0 = 0; y0 < ws; y0 += 4) {
-                uint8_t v[4];
+        // The 64 lanes of a gather take an 8x8 block of patch pixels (lane = 8 * row + column inside the block), four blocks in
+        // flight. A gather costs about as much as the number of distinct 128-byte lines it touches: a patch ROW of a rotated
+        // marker crosses 56 image rows, an 8x8 block of the patch covers about 21 x 21 source pixels whatever the rotation.
+        const int bxl = lane & 7, byl = lane >> 3;
+        const int nb = (ws + 7) >> 3, nblocks = nb * nb;
+        for (int b0 = 0; b0 < nblocks; b0 += 4) {
+            uint8_t v[4];
+            int px[4], py[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int y = y0 + q;
-                    // nearest-neighbour gather (BORDER_CONSTANT 0), cvRound = round-half-even. cv::warpPerspective forms
-                    // Wd = 1/W (correctly rounded), fX = X*Wd, cvRound(fX). The full IEEE division is the most expensive
-                    // part of the pixel, so the reciprocal is first taken from v_rcp_f64 + two Newton steps (a few ulp);
-                    // the rounded integers can only differ from the reference's when fX or fY lies within ~1e-11 of a
-                    // rounding boundary, and every pixel within 1e-6 of one (or out of range) takes the exact path.
-                    const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
-                    const double Wq = W0 + cx, nx = X0 + ax, ny = Y0 + bx;
-                    double r = __builtin_amdgcn_rcp(Wq);
-                    r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
-                    r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
-                    double fX = nx * r, fY = ny * r;
-                    const bool sure = fabs(__builtin_amdgcn_fract(fX) - 0.5) > 1e-6 && fabs(__builtin_amdgcn_fract(fY) - 0.5) > 1e-6 &&
-                                      fabs(fX) < 1e9 && fabs(fY) < 1e9;
-                    if (!sure) {
-                        const double Wd = Wq != 0 ? 1. / Wq : 0;
-                        fX = fmax((double)INT_MIN, fmin((double)INT_MAX, nx * Wd));
-                        fY = fmax((double)INT_MIN, fmin((double)INT_MAX, ny * Wd));
-                    }
-                    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
-                    v[q] = 0;
-                    if (y < ws && X >= 0 && X < W && Y >= 0 && Y < H) v[q] = src[(size_t)Y * a.row_stride + X];
+            for (int q = 0; q < 4; q++) {
+                const int bi = b0 + q, BY = bi / nb, BX = bi - BY * nb;
+                const int x = BX * 8 + bxl, y = BY * 8 + byl;
+                px[q] = x, py[q] = (bi < nblocks && x < ws && y < ws) ? y : -1;
+                // nearest-neighbour gather (BORDER_CONSTANT 0), cvRound = round-half-even. cv::warpPerspective forms
+                // Wd = 1/W (correctly rounded), fX = X*Wd, cvRound(fX). The full IEEE division is the most expensive
+                // part of the pixel, so the reciprocal is first taken from v_rcp_f64 + two Newton steps (a few ulp);
+                // the rounded integers can only differ from the reference's when fX or fY lies within ~1e-11 of a
+                // rounding boundary, and every pixel within 1e-6 of one (or out of range) takes the exact path.
+                const double ax = m0 * x, bx = m3 * x, cx = m6 * x;
+                const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
+                const double Wq = W0 + cx, nx = X0 + ax, ny = Y0 + bx;
+                double r = __builtin_amdgcn_rcp(Wq);
+                r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+                r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+                double fX = nx * r, fY = ny * r;
+                const bool sure = fabs(__builtin_amdgcn_fract(fX) - 0.5) > 1e-6 && fabs(__builtin_amdgcn_fract(fY) - 0.5) > 1e-6 &&
+                                  fabs(fX) < 1e9 && fabs(fY) < 1e9;
+                if (!sure) {
+                    const double Wd = Wq != 0 ? 1. / Wq : 0;
+                    fX = fmax((double)INT_MIN, fmin((double)INT_MAX, nx * Wd));
+                    fY = fmax((double)INT_MIN, fmin((double)INT_MAX, ny * Wd));
                 }
+                const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+                v[q] = 0;
+                if (py[q] >= 0 && X >= 0 && X < W && Y >= 0 && Y < H) v[q] = src[(size_t)Y * a.row_stride + X];
+            }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int y = y0 + q;
-                    if (y < ws) {
-                        patch[y * ws + x] = v[q];
-                        if (bytes)
-                            atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
-                        else
-                            atomicAdd(&myhist[v[q]], 1u);
-                    }
+            for (int q = 0; q < 4; q++) {
+                if (py[q] >= 0) {
+                    patch[py[q] * ws + px[q]] = v[q];
+                    if (bytes)
+                        atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
+                    else
+                        atomicAdd(&myhist[v[q]], 1u);
                 }
             }
         }
