@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# Three batches in flight use six HIP streams (a main and a side stream per lane). The HIP runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise. Must be set before the runtime starts
+# (INTEGRATION.md "deployment knobs"; measured: depth 3 = 309.7k fps with 4 queues, 343.8k with 8).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -189,7 +194,7 @@ def main():
                     help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
-    ap.add_argument("--depth", type=int, default=2,
+    ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
@@ -384,7 +389,7 @@ def main():
                                     + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
                                    + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else ""),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
-                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth, "parallelism": "frames sharded 1 stream/GPU"
+                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "frames sharded 1 stream/GPU"
                        + (", RCCL gather of marker blocks per step" if world > 1 else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
