@@ -698,8 +698,8 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     hipEvent_t* ev = h->ev[h->tsets % TSETS];
     const bool tm = h->timing;
 #define MARK(i) do { if (tm) (void)hipEventRecord(ev[i], s); } while (0)
-    MARK(K_THRESHOLD);
-    if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));
+    if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));   // threshold kernels of the lanes run one after the other
+    MARK(K_THRESHOLD);   // after that wait: the interval is this batch's own threshold kernel
     {
         const int rc_ = run_threshold(h, s, gray_dev, g, nframes, dp);
         if (rc_) return rc_;

@@ -128,7 +128,9 @@ int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int width, int heig
                     int* n_out);
 
 /* Same for a batch of nframes equally sized frames (frame f at frames + f*frame_stride).
- * frames_on_device != 0: `frames` is a device pointer (frames already resident in HBM).
+ * frames_on_device != 0: `frames` is a device pointer (frames already resident in HBM). The kernels read it on the
+ *                       handle's stream: frames produced on another stream must be complete before the call (synchronise
+ *                       that stream, or run the handle on it with arucohip_set_stream).
  * out_on_device   != 0: `out` (nframes*cap markers) and `n_out` (nframes int32) are device pointers, the call is
  *                       asynchronous on the handle's stream and reports only launch errors; otherwise host arrays and
  *                       the call returns when the results are there. */
