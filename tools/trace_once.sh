@@ -6,8 +6,7 @@ OUT=gpurun_out/trace_${1:-x}
 mkdir -p $OUT
 rm -rf /tmp/p_tr
 timeout -k 10 400 rocprofv3 --kernel-trace --kernel-include-regex "ah::" --output-format csv -d /tmp/p_tr -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --depth 1 ${BENCH_ARGS:-} > $OUT/run.log 2>&1
-cp /tmp/p_tr/*/*kernel_trace.csv $OUT/kernel_trace.csv
-python3 - $OUT/kernel_trace.csv <<'PY'
+python3 - /tmp/p_tr/*/*kernel_trace.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
