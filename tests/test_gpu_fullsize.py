@@ -114,3 +114,55 @@ def test_pipelined_and_permuted_batches_keep_every_frames_bytes(env):
                 assert a[f, :c[f]].tobytes() == ref_a[f, :c[f]].tobytes(), (i, f)
     finally:
         h.close()
+
+
+def test_all_128_4k_board_frames_equal_the_oracle(env):
+    """Config 4 at bench size: 128 frames 3840x2160 of the 6x4 board (bench.py's stream, seed 4711), MarkerDetector on every frame
+    and the batched BoardDetector pose against the oracle; the pose also against the rendering pose (ground truth)."""
+    from tests.util import load_case
+    capi, orc, torch = env["capi"], env["orc"], env["torch"]
+    from aruco_amd import synth
+    W, H, NB = 3840, 2160, 128
+    _, doc = load_case("board")
+    bc = doc["board_conf"]
+    K = np.array(doc["intrinsics"]["K"], np.float32).reshape(3, 3)          # CameraParameters::resize (cameraparameters.cpp:173-178)
+    K[0, 0] *= np.float32(W / 640.0); K[0, 2] *= np.float32(W / 640.0)
+    K[1, 1] *= np.float32(H / 480.0); K[1, 2] *= np.float32(H / 480.0)
+    Kf = K.reshape(-1)
+    dist = [0.0] * 5
+    frames, poses = synth.make_board_stream(NB, bc["ids"], bc["obj"], Kf, width=W, height=H, seed=4711, device="cuda")
+    torch.cuda.synchronize()
+    h = capi.Handle(W, H, max_batch=NB)
+    try:
+        out = torch.zeros((NB, CAP * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(NB, dtype=torch.int32, device="cuda")
+        h.detect_batch_device(frames.data_ptr(), NB, W, H, out.data_ptr(), CAP, cnt.data_ptr())
+        h.batch_status()
+        boards = h.board_detect_batch(NB, bc["ids"], bc["obj"], bc["info_type"], Kf, dist, 0.039)
+        torch.cuda.synchronize()
+        arr = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(NB, CAP)
+        n = cnt.cpu().numpy()
+    finally:
+        h.close()
+    host = frames.cpu().numpy()
+
+    def ref(f):
+        m = orc.Oracle().detect(host[f])
+        return m, orc.board_detect(m, bc["ids"], bc["obj"], bc["info_type"], Kf, dist, 0.039)
+
+    with cf.ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        refs = list(ex.map(ref, range(NB)))
+    for f in range(NB):
+        got, (exp, ob) = arr[f, :n[f]], refs[f]
+        assert [int(m["id"]) for m in got] == [m["id"] for m in exp], f
+        assert len(got) >= 20
+        for a, b in zip(got, exp):
+            ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+            assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4, f          # 1e-4 relative (north_star)
+        bb = boards[f]
+        assert bb["has_pose"] == 1 and ob["has_pose"] == 1 and bb["n_markers"] == len(ob["markers"])
+        assert abs(bb["prob"] - ob["prob"]) < 1e-6
+        assert rel_err(bb["rvec"], ob["rvec"]) < 1e-4 and rel_err(bb["tvec"], ob["tvec"]) < 1e-4, f
+        # ground truth: the pose the frame was rendered with (corner detection noise: 1 % of the distance is ample)
+        rv, tv = poses[f]
+        assert np.linalg.norm(bb["tvec"] - tv) < 0.01 * np.linalg.norm(tv), f
