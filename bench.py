@@ -373,7 +373,7 @@ def main():
         # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config in (2, 3):     # the committed PMC passes are of the 1080p stream
             try:
                 tj = json.load(open(tpath))
                 if dom in tj.get("kernels", {}):
