@@ -482,7 +482,7 @@ constexpr int CHUNK = 8;   // steps taken between two looks at the block edge (d
 // steps) are only stored there. ck_at(n / CK) is where this lane's checkpoint goes.
 template <bool HOLE, int LANES, typename CkAt>
 __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t* rows, int lane, bool live, uint32_t tkey,
-                                        uint32_t pos0, uint32_t pos1, uint32_t lim, uint32_t& pos, uint32_t& n, int& s, CkAt ck_at,
+                                        uint32_t pos0, uint32_t pos1, uint32_t lim, uint32_t nmax, uint32_t& pos, uint32_t& n, int& s, CkAt ck_at,
                                         const TileBlock* preloaded = nullptr) {
     TileBlock blk;
     if (preloaded)
@@ -499,7 +499,13 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
             const int lx = x - blk.bx, ly = y - blk.by;
             const bool near = (lx < 1 + CHUNK && blk.bx > 0) || (lx > 30 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
                               (ly > 30 - CHUNK && blk.by < maxby);
-            static_assert(true, "");
+            // A closed 8-connected border that reaches Chebyshev distance d from its start has at least 2 d points (every step moves
+            // at most one pixel in that metric, and the border returns): at 2 d >= nmax the size filter's verdict is known and the
+            // walk ends here instead of after nmax steps.
+            {
+                const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
+                if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, res = WR_BAD;
+            }
             if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
         }
         const uint32_t* rb = rows + lane - (blk.by + 1) * LANES;   // row y of the image sits at rb[y * LANES]
@@ -603,7 +609,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
         const uint32_t pos1 = pos0 + tb_dpos(s & 7);
         uint32_t pos = pos0, n = 0;
         // all lanes of the wave step together; a lane that finished idles until the longest walk of the wave ends
-        int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, pos, n, s,
+        int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s,
                                      [&](uint32_t q) { return ck0 + q * 64 + lane; }, &blk);
         if (!live) res = WR_BAD;
         // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
@@ -684,7 +690,7 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
         const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * plane_tiles;
         uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
         const uint32_t lim = min(n + (uint32_t)a.gen_steps, nmax);
-        const int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, pos, n, s, [&](uint32_t q) { return ck + q; });
+        const int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s, [&](uint32_t q) { return ck + q; });
         if (live && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
             uint32_t at;
             keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
@@ -831,6 +837,10 @@ __device__ __forceinline__ void wave_argmax_first(uint32_t val, uint32_t idx, ui
     *first_idx = wave_min_u32((idx != 0xFFFFFFFFu && val == mv) ? idx : 0xFFFFFFFFu);
 }
 
+#ifndef EMIT_LANES_N
+#define EMIT_LANES_N 32
+#endif
+constexpr int EMIT_LANES = EMIT_LANES_N;   // lanes that emit points at a time (each needs a 32x32 block in LDS)
 constexpr int QP_LDS = 1024;   // points of a border kept in LDS; longer borders are scanned in HBM (their pool range)
 
 struct QuadArgs {
@@ -866,8 +876,11 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
         // Every lane resumes the walk at one checkpoint and records CK = 16 points. The neighbourhoods come from the lane's own
         // 32x32-pixel block in LDS (one load of eight 16-byte pieces instead of six dependent tile reads per step): a block
         // centred on the checkpoint leaves at least 11 steps of room, so it is re-centred once, after 8 steps, where needed.
+        // EMIT_LANES lanes at a time: the kernel's speed follows its occupancy (12 KB of LDS per wave = 12 waves per CU measured
+        // 0.67 ms, 24 KB 1.08 ms), and the blocks of a half wave cost 4 KB instead of 8; the emission is a fifth of the kernel
         const int maxbx = (a.tnx - 4) * 8, maxby = (a.tny - 4) * 8;
-        for (int k0 = 0; k0 < ncp; k0 += WAVE) {
+        for (int k0 = 0; k0 < ncp; k0 += EMIT_LANES) {
+            if (lane >= EMIT_LANES) continue;
             const int k = k0 + lane;
             const bool live = k < ncp;
             const uint32_t c = ckp[live ? k : 0];
@@ -875,17 +888,17 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
             int s = (int)(c >> 28);
             const int n0 = k * CK, n1 = live ? min(n0 + CK, count) : n0;
             TileBlock blk;
-            tb_load<WAVE>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
 #pragma unroll
             for (int j = 0; j < CK; j++) {
                 if (j == CK / 2) {
                     const int lx = (int)(pos & 0xFFFFu) - blk.bx, ly = (int)(pos >> 16) - blk.by;
                     const bool near = (lx < 1 + CK / 2 && blk.bx > 0) || (lx > 30 - CK / 2 && blk.bx < maxbx) || (ly < 1 + CK / 2 && blk.by > 0) ||
                                       (ly > 30 - CK / 2 && blk.by < maxby);
-                    if (near && n0 + j < n1) tb_load<WAVE>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+                    if (near && n0 + j < n1) tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
                 }
                 if (n0 + j < n1) {
-                    const uint32_t m = tb_mask<WAVE>(rows, lane, blk, pos);
+                    const uint32_t m = tb_mask<EMIT_LANES>(rows, lane, blk, pos);
                     const uint32_t sh = (uint32_t)(s + 1) & 7u;
                     const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
                     const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
@@ -1058,7 +1071,7 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     latency_bound_priority();
     __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
-    __shared__ uint32_t rows[TB_ROWS * WAVE];        // one 32x32-pixel block per lane for the point emission
+    __shared__ uint32_t rows[TB_ROWS * EMIT_LANES];  // one 32x32-pixel block per emitting lane
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
     __shared__ int s_outn;

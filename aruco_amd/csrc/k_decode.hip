@@ -220,8 +220,12 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
 // histogram serialise 50-fold. 32 private copies (one per lane pair) with byte counters packed four to a word cost the same
 // 8 KB as 8 word-sized copies: a copy sees at most 2 * (ws / 8)^2 <= 128 pixels when ws <= 64, so a byte never
 // overflows into its neighbour; wider patches use word counters in 8 copies.
-constexpr int HCOPIES = 32, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+3) + 1 so that copies start in different banks
-constexpr int HWCOPIES = 8, HWPITCH = 257;
+#ifndef HCOPIES_N
+#define HCOPIES_N 32
+#endif
+constexpr int HCOPIES = HCOPIES_N, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+3) + 1 so that copies start in different banks
+constexpr int HWCOPIES = HCOPIES / 4, HWPITCH = 257;
+constexpr int HLANES = WAVE / HCOPIES;            // lanes that share a copy
 static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     latency_bound_priority();
@@ -235,12 +239,12 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         const uint32_t e = a.cand_list[idx];
         const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
         for (int i = lane; i < HCOPIES * HPITCH; i += WAVE) hist[i] = 0;
-        const bool bytes = a.ws <= 64;
+        const bool bytes = HLANES * ((a.ws + 7) / 8) * ((a.ws + 7) / 8) < 256;   // pixels a copy can see: a byte counter must hold them
         if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
         __syncthreads();
         const int ws = a.ws, npx = ws * ws;
         uint8_t* patch = a.patches + (size_t)idx * npx;
-        uint32_t* myhist = bytes ? hist + (lane >> 1) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
+        uint32_t* myhist = bytes ? hist + (lane / HLANES) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
         const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
         // The 64 lanes of a gather take an 8x8 block of patch pixels (lane = 8 * row + column inside the block), four blocks in
         // flight. A gather costs about as much as the number of distinct 128-byte lines it touches: a patch ROW of a rotated

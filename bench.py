@@ -19,10 +19,11 @@ import os
 import sys
 import time
 
-# Three batches in flight use six HIP streams (a main and a side stream per lane). The HIP runtime maps streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise. Must be set before the runtime starts
-# (INTEGRATION.md "deployment knobs"; measured: depth 3 = 309.7k fps with 4 queues, 343.8k with 8).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# d batches in flight use 2 d HIP streams (a main and a side stream per worker) next to the handle's own two and torch's. The HIP
+# runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise. Must be set before the
+# runtime starts (INTEGRATION.md "deployment knobs"; measured: config 2 at depth 3 = 309.7k fps with 4 queues, 343.8k with 8; config 4 at
+# depth 3 = 56.0k with 8 queues — two workers' border walks shared a queue — 73.8k with 12 or more).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -194,8 +195,9 @@ def main():
                     help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
-    ap.add_argument("--depth", type=int, default=3,
-                    help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time; default 3, "
+                         "config 4: 6 (its 128-frame batches wait on a 5000-step border walk: more of them in flight fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
@@ -258,7 +260,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream shared by the library, its events and RCCL
     torch.cuda.set_stream(stream)
     handle.set_stream(stream.cuda_stream)
-    depth = max(1, args.depth)
+    depth = args.depth if args.depth > 0 else (6 if args.config == 4 else 3)
     outs = [torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev) for _ in range(depth)]
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
     out, cnt = outs[0], cnts[0]
