@@ -63,7 +63,7 @@ SYMBOLS = [
     "arucohip_get_thresholded", "arucohip_get_candidates", "arucohip_threshold", "arucohip_detect_rectangles",
     "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
-    "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_kernel_name",
+    "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_threshold_exec_ms", "arucohip_kernel_name",
     "arucohip_debug_counters", "arucohip_board_detect_batch",
     "arucohip_gl_modelview", "arucohip_ogre_pose", "arucohip_gl_projection", "arucohip_ogre_projection",
     "arucohip_detect_bgr", "arucohip_detect_batch_bgr", "arucohip_bgr_to_gray", "arucohip_set_dictionary",
@@ -125,6 +125,7 @@ def load():
     L.arucohip_stage_name.argtypes = [i]
     L.arucohip_enable_timing.argtypes = [vp, i]
     L.arucohip_kernel_times.argtypes = [vp, vp, i]
+    L.arucohip_threshold_exec_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.arucohip_kernel_name.argtypes = [i]
     L.arucohip_debug_counters.argtypes = [vp, vp]
     L.arucohip_board_detect_batch.argtypes = [vp, i, vp, vp, i, i, vp, vp, i, f, f, i, vp, vp]
@@ -452,6 +453,12 @@ class Handle:
         ms = (C.c_float * 16)()
         n = self.L.arucohip_kernel_times(self.h, ms, 16)
         return {self.L.arucohip_kernel_name(i).decode(): ms[i] for i in range(n)}
+
+    def threshold_exec_ms(self):
+        """(total ms, launches) of the wide threshold kernel since enable_timing(True), from the device clock stamps of its waves."""
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.L.arucohip_threshold_exec_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def debug_counters(self):
         c = np.zeros(8, np.uint32)

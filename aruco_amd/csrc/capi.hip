@@ -240,6 +240,7 @@ static void free_all(arucohip_handle* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
+    hipFree(h->buf.thr_stamps), hipFree(h->buf.thr_acc);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.trig), hipFree(h->buf.gen_buf), hipFree(h->zero_block), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
     hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
@@ -312,6 +313,12 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_markers = lim->markers_per_frame;
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
+    {   // timing stamps of the wide threshold kernel: its finest grid is one wave per 1024-px strip and 16 rows
+        const size_t waves = (size_t)tile_strips(lim->max_width) * ((lim->max_height + 15) / 16) * F;
+        ALLOC(b.thr_stamps, 2 * waves * sizeof(uint64_t));
+        ALLOC(b.thr_acc, 2 * sizeof(uint64_t));
+        b.thr_stamp_on = 0;
+    }
     const size_t bits_bytes = P * (size_t)tiles_x(lim->max_width) * tiles_y(lim->max_height) * sizeof(uint64_t) + 64;
     ALLOC(b.tiles, bits_bytes);
     if ((e = hipMemset(b.tiles, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad tiles must read as zero
@@ -454,6 +461,17 @@ int arucohip_enable_timing(arucohip_handle* h, int on) {
     h->timing = on != 0;
     h->tsets = 0;
     for (auto* k : h->kids) k->timing = h->timing, k->tsets = 0;
+    // device-clock stamps of the wide threshold kernel (k_threshold.hip): taken while timing is on, accumulators restart with it
+    auto arm = [&](arucohip_handle* x) {
+        x->buf.thr_stamp_on = on != 0 && x->buf.thr_stamps && x->buf.thr_acc;
+        if (on && x->buf.thr_acc) {
+            hipSetDevice(x->device);
+            (void)hipStreamSynchronize(x->stream);
+            (void)hipMemset(x->buf.thr_acc, 0, 2 * sizeof(uint64_t));
+        }
+    };
+    arm(h);
+    for (auto* k : h->kids) arm(k);
     for (auto* l : h->lanes) arucohip_enable_timing(l, on);
     return ARUCOHIP_OK;
 }
@@ -493,6 +511,31 @@ int arucohip_stage_times(arucohip_handle* h, float* ms, int cap) {
     return STAGE_COUNT;
 }
 const char* arucohip_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
+int arucohip_threshold_exec_ms(arucohip_handle* h, double* total_ms, int* launches) {
+    if (!h || !total_ms || !launches) return ARUCOHIP_E_INVALID;
+    hipSetDevice(h->device);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) return fail(h, ARUCOHIP_E_HIP, "no wall clock rate");
+    unsigned long long ticks = 0, n = 0;
+    auto add = [&](arucohip_handle* w) -> int {
+        if (!w->buf.thr_acc) return ARUCOHIP_OK;
+        unsigned long long v[2] = {0, 0};
+        HIPCHK(h, hipStreamSynchronize(w->stream));
+        HIPCHK(h, hipMemcpy(v, w->buf.thr_acc, sizeof(v), hipMemcpyDeviceToHost));
+        ticks += v[0], n += v[1];
+        return ARUCOHIP_OK;
+    };
+    int rc = add(h);
+    for (auto* k : h->kids) if (rc == ARUCOHIP_OK) rc = add(k);
+    for (auto* l : h->lanes) {
+        if (rc == ARUCOHIP_OK) rc = add(l);
+        for (auto* k : l->kids) if (rc == ARUCOHIP_OK) rc = add(k);
+    }
+    if (rc != ARUCOHIP_OK) return rc;
+    *total_ms = (double)ticks / (double)khz, *launches = (int)n;
+    return ARUCOHIP_OK;
+}
+
 int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap) {
     if (!h) return 0;
     collect_times(h);

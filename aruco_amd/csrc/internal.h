@@ -139,6 +139,9 @@ struct Buffers {
     uint32_t* gen_cnt;     // counters of the long-walk generation lists (k_contours.hip), zeroed per batch
     ContourDesc* cdesc;
     short2* pool;
+    uint64_t* thr_stamps;   // timing: per-wave device-clock stamps of the wide threshold kernel [2 * waves]
+    uint64_t* thr_acc;      // timing: {clock ticks, launches} accumulated by stamp_reduce_kernel
+    int thr_stamp_on;       // stamps are taken (arucohip_enable_timing)
     uint32_t* walk_scratch; // checkpoint rings of the long walks [P][2][LONG_CAP][max_contour/16]
     uint4* node;            // [P][cap_raw] waypoint records of the segment pipeline
     unsigned long long* stamp; // [P][cap_raw] (start key, start node, offset) of the start that owns the node

@@ -42,6 +42,7 @@ struct ThrArgs {
     uint64_t* tiles;
     uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
     int nstrips;          // 128-tile strips per tile row
+    uint64_t* stamps;     // timing only (else null): first / last device-clock reading of every wave of the wide kernel
 };
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -269,7 +270,7 @@ constexpr int WSTRIP = 1024;    // pixels per wave and row; strips start on 1-Ki
 constexpr uint32_t SEL02 = 0x0C020C00u, SEL13 = 0x0C030C01u;   // v_perm selectors: bytes (0, 2) / (1, 3) of a dword as u16 pairs
 
 template <int R, int PF, int SEGW>
-__global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
+__device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
     static_assert(R >= 1 && R <= 4 && PF >= 1 && PF <= 7, "one halo dword per side; the shortest segment has 8 rows");
     constexpr int RING = 2 * R + 1, N = RING + PF;
     const int lane = threadIdx.x;
@@ -436,6 +437,39 @@ __global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
     }
 }
 
+// With hipEvent timing on, every wave also leaves the device clock (constant rate, hipDeviceAttributeWallClockRate) at its start and
+// after its last store; stamp_reduce_kernel turns them into the launch's execution span. With several batches in flight the hipEvent
+// interval around the launch also contains the time the dispatch waits for wave slots other batches' kernels hold; the span from the
+// first wave's start to the last wave's end is what rocprofv3 reports per dispatch, and what the roofline fraction is about.
+template <int R, int PF, int SEGW>
+__global__ __launch_bounds__(64) void threshold_wide_kernel(ThrArgs a) {
+    uint64_t t0 = 0;
+    if (a.stamps) t0 = wall_clock64();
+    threshold_wide_body<R, PF, SEGW>(a);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);   // the wave's stores have left
+        const uint64_t t1 = wall_clock64();
+        if (threadIdx.x == 0) {
+            const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            a.stamps[2 * w] = t0, a.stamps[2 * w + 1] = t1;
+        }
+    }
+}
+
+// acc[0] += last end - first start of the launch's nwaves stamps, acc[1] += 1
+__global__ __launch_bounds__(1024) void stamp_reduce_kernel(const uint64_t* __restrict__ stamps, size_t nwaves, unsigned long long* acc) {
+    __shared__ unsigned long long smin[1024], smax[1024];
+    unsigned long long lo = ~0ull, hi = 0;
+    for (size_t i = threadIdx.x; i < nwaves; i += 1024) lo = min(lo, (unsigned long long)stamps[2 * i]), hi = max(hi, (unsigned long long)stamps[2 * i + 1]);
+    smin[threadIdx.x] = lo, smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) smin[threadIdx.x] = min(smin[threadIdx.x], smin[threadIdx.x + st]), smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && smax[0] > smin[0]) acc[0] += smax[0] - smin[0], acc[1] += 1;
+}
+
 // the non-empty-tile bitmap for the paths whose kernel does not write it (narrow / FIXED / caller-supplied binary image): one
 // wave per (strip, tile row, plane) reads the strip's 128 tiles
 __global__ __launch_bounds__(64) void tile_bitmap_kernel(const uint64_t* __restrict__ tiles, uint64_t* __restrict__ tile_bits, int tnx, int tny, int nstrips) {
@@ -457,7 +491,7 @@ void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Bu
 
 // returns true if the kernel that ran also wrote the non-empty-tile bitmap
 template <int R>
-static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
+static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes, unsigned long long* stamp_acc) {
     dim3 grid((a.width + STRIP - 1) / STRIP, (a.height + SEG - 1) / SEG, nframes);
     constexpr bool CAN16 = R <= 5;
     const long lim = (long)(256 + abs(a.idelta)) * a.n + a.n_half;
@@ -470,13 +504,18 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes) {
             // launches can afford)
             const int strips = (a.width + WSTRIP - 1) / WSTRIP;
             const long waves128 = (long)strips * ((a.height + 127) / 128) * nframes;
+            int segs;
             if (waves128 >= 512) {
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), dim3(strips, (a.height + 127) / 128, nframes), dim3(64), 0, s, a);
+                segs = (a.height + 127) / 128;
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             } else if (waves128 * 4 >= 512) {
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 32>), dim3(strips, (a.height + 31) / 32, nframes), dim3(64), 0, s, a);
+                segs = (a.height + 31) / 32;
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 32>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             } else {
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 16>), dim3(strips, (a.height + 15) / 16, nframes), dim3(64), 0, s, a);
+                segs = (a.height + 15) / 16;
+                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 16>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             }
+            if (a.stamps) hipLaunchKernelGGL(stamp_reduce_kernel, dim3(1), dim3(1024), 0, s, a.stamps, (size_t)strips * segs * nframes, stamp_acc);
             return true;
         }
     }
@@ -495,6 +534,7 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
     a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width), a.wide_ok = b.tune.threshold_wide;
     a.idelta = 0, a.n = 1, a.n_half = 0;
+    a.stamps = b.thr_stamp_on ? b.thr_stamps : nullptr;
     a.fast = ((g.width | (int)(g.row_stride & 3) | (int)(g.frame_stride & 3) | (int)((uintptr_t)gray & 3)) & 3) == 0;
     a.fast16 = g.width >= 16 && ((g.width | (int)(g.row_stride & 15) | (int)(g.frame_stride & 15) | (int)((uintptr_t)gray & 15) | (int)((uintptr_t)b.thres & 15)) & 15) == 0;
 }
@@ -516,21 +556,21 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
         }
         a.n = p.block[t] * p.block[t], a.n_half = a.n / 2, a.idelta = p.idelta;
         switch (p.block[t] / 2) {
-            case 1: bitmap_done &= launch_adpt<1>(s, a, nframes); break;
-            case 2: bitmap_done &= launch_adpt<2>(s, a, nframes); break;
-            case 3: bitmap_done &= launch_adpt<3>(s, a, nframes); break;
-            case 4: bitmap_done &= launch_adpt<4>(s, a, nframes); break;
-            case 5: bitmap_done &= launch_adpt<5>(s, a, nframes); break;
-            case 6: bitmap_done &= launch_adpt<6>(s, a, nframes); break;
-            case 7: bitmap_done &= launch_adpt<7>(s, a, nframes); break;
-            case 8: bitmap_done &= launch_adpt<8>(s, a, nframes); break;
-            case 9: bitmap_done &= launch_adpt<9>(s, a, nframes); break;
-            case 10: bitmap_done &= launch_adpt<10>(s, a, nframes); break;
-            case 11: bitmap_done &= launch_adpt<11>(s, a, nframes); break;
-            case 12: bitmap_done &= launch_adpt<12>(s, a, nframes); break;
-            case 13: bitmap_done &= launch_adpt<13>(s, a, nframes); break;
-            case 14: bitmap_done &= launch_adpt<14>(s, a, nframes); break;
-            default: bitmap_done &= launch_adpt<15>(s, a, nframes); break;
+            case 1: bitmap_done &= launch_adpt<1>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 2: bitmap_done &= launch_adpt<2>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 3: bitmap_done &= launch_adpt<3>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 4: bitmap_done &= launch_adpt<4>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 5: bitmap_done &= launch_adpt<5>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 6: bitmap_done &= launch_adpt<6>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 7: bitmap_done &= launch_adpt<7>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 8: bitmap_done &= launch_adpt<8>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 9: bitmap_done &= launch_adpt<9>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 10: bitmap_done &= launch_adpt<10>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 11: bitmap_done &= launch_adpt<11>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 12: bitmap_done &= launch_adpt<12>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 13: bitmap_done &= launch_adpt<13>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            case 14: bitmap_done &= launch_adpt<14>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
+            default: bitmap_done &= launch_adpt<15>(s, a, nframes, (unsigned long long*)b.thr_acc); break;
         }
     }
     if (!bitmap_done) launch_tile_bitmap(s, g, nframes * p.nthr, b);

@@ -20,10 +20,13 @@ import sys
 import time
 
 # d batches in flight use 2 d HIP streams (a main and a side stream per worker) next to the handle's own two and torch's. The HIP
-# runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise. Must be set before the
-# runtime starts (INTEGRATION.md "deployment knobs"; measured: config 2 at depth 3 = 309.7k fps with 4 queues, 343.8k with 8; config 4 at
-# depth 3 = 56.0k with 8 queues — two workers' border walks shared a queue — 73.8k with 12 or more).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise. The variable must be in
+# the environment before the runtime starts, so main() sets it right after parsing the arguments (INTEGRATION.md "deployment knobs").
+# Measured: config 2 at depth 3 = 309.7k fps with 4 queues, 343.8k with 8, 320-331k with 16 (more kernels share the chip at once and
+# all of them stretch); config 4 = 56.0k with 8 queues at depth 3 (two workers' border walks shared a queue), 73.8k with 12 or more,
+# 94.4k with 16 queues and six batches in flight (its batches wait on one 5000-step border walk each).
+def default_hw_queues(config):
+    return "16" if config == 4 else "8"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -202,6 +205,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", default_hw_queues(args.config))   # before torch / HIP start; the launched ranks inherit it
 
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not in_rank:
@@ -331,12 +335,14 @@ def main():
         handle.batch_status()                   # raises on any device-side list overflow
     elapsed = adist.max_over_ranks(elapsed, dev)
     ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams over the timed steps
+    exec_ms, exec_n = handle.threshold_exec_ms()  # the threshold launches of the timed steps by the device clock (first wave in, last wave out)
     chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
     handle.enable_timing(False)
     # Outside the timed region: the same kernels one batch at a time. With batches in flight a kernel's event interval also
     # contains the time it shares the chip with the other batch's kernels; the isolated durations are what rocprofv3 shows
     # per dispatch when nothing else runs.
     ktimes_iso = ktimes
+    iso_exec_ms, iso_exec_n = exec_ms, exec_n
     if depth > 1:
         handle.enable_timing(True)
         for i in range(3):
@@ -344,6 +350,7 @@ def main():
                                      cnts[0].data_ptr(), K=K, dist=dcoef, marker_size=msize, frames_on_device=frames_host is None)
             handle.wait(t)
         ktimes_iso = handle.kernel_times()
+        iso_exec_ms, iso_exec_n = handle.threshold_exec_ms()
         handle.enable_timing(False)
 
     # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
@@ -369,7 +376,13 @@ def main():
         # dominant kernel = the longest when a batch runs alone; with batches in flight the event intervals of the short dependent
         # kernels are mostly waiting for wave slots the other batches' kernels hold, not work
         dom = max(ktimes_iso, key=lambda k: ktimes_iso[k])
+        # Duration of the dominant kernel's launches inside the timed region. For the threshold kernel the device-clock span of
+        # each launch (what rocprofv3 reports per dispatch); its hipEvent interval is also printed (event_interval_ms): with
+        # batches in flight that one contains the time the dispatch queues behind the other batches' kernels.
         dom_ms = ktimes[dom]
+        event_ms = dom_ms
+        if dom == "threshold_kernel" and exec_n > 0:
+            dom_ms = exec_ms / exec_n
         achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes of the dominant kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
         # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
@@ -404,7 +417,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * per_launch, "frames_per_launch": per_launch,
-                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4), "isolated_launch_ms": round(iso_ms, 4),
+                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4),
+                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the timed steps" % exec_n
+                         if (dom == "threshold_kernel" and exec_n > 0) else "hipEvent interval on the launch stream",
+                         "event_interval_ms": round(event_ms, 4), "frac_event_interval": round(ALG_BYTES_PER_FRAME * per_launch / (event_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if event_ms > 0 else None,
+                         "isolated_launch_ms": round(iso_ms, 4),
+                         "isolated_launch_ms_device_clock": round(iso_exec_ms / iso_exec_n, 4) if (dom == "threshold_kernel" and iso_exec_n > 0) else None,
                          "frac_isolated": round(ALG_BYTES_PER_FRAME * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
                          "frac_own_bytes": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
                          "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5)},

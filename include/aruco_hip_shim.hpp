@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <iterator>
 #include <fstream>
+#include <type_traits>
 #include <vector>
 
 #include "arucohip.h"
@@ -584,6 +585,17 @@ public:
                 bool setYPerpendicular = false) {
         detect(input, detectedMarkers, camParams.CameraMatrix, camParams.Distorsion, markerSizeMeters, setYPerpendicular);
     }
+
+#if ARUCOHIP_HAVE_OPENCV
+    // With the real OpenCV the reference takes cv::InputArray (markerdetector.h:102): anything that is not already a cv::Mat
+    // (std::vector<uchar>, cv::Mat_, cv::UMat ...) comes through getMat(). This branch cannot be compiled in the build container
+    // (no OpenCV there): DESIGN.md lists it as untested.
+    template <class A, class = typename std::enable_if<!std::is_convertible<const A&, const cv::Mat&>::value>::type>
+    void detect(const A& input, std::vector<Marker>& detectedMarkers, cv::Mat camMatrix = cv::Mat(), cv::Mat distCoeff = cv::Mat(),
+                float markerSizeMeters = -1, bool setYPerpendicular = false) {
+        detect(cv::_InputArray(input).getMat(), detectedMarkers, camMatrix, distCoeff, markerSizeMeters, setYPerpendicular);
+    }
+#endif
 
     // markerdetector.h:78
     typedef int (*MarkerdetectorFunc)(const cv::Mat& in, int& nRotations);

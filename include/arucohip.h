@@ -255,6 +255,13 @@ int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* 
 int arucohip_calculate_extrinsics(arucohip_handle* h, arucohip_marker_t* markers, int n, const float* K, const float* dist,
                                   int ndist, float marker_size, int y_perpendicular);
 
+/* Execution time of the dominant streaming kernel (the 16-pixel-per-lane adaptive threshold kernel) from the device's constant-rate
+ * clock: every wave leaves its first and last reading, *total_ms = sum over the launches since arucohip_enable_timing(h, 1) of
+ * (last wave's end - first wave's start), *launches = their number (0 when another threshold kernel ran: use the event times).
+ * Unlike the hipEvent interval of arucohip_kernel_times this excludes the time a dispatch queues behind other batches' kernels
+ * when several batches are in flight; it is what rocprofv3 --kernel-trace reports per dispatch. No reference counterpart. */
+int arucohip_threshold_exec_ms(arucohip_handle* h, double* total_ms, int* launches);
+
 /* Per-stage device time per batch in milliseconds (hipEvent pairs on the handle's stream), the reference's
  * ARUCO_MARKER_BENCHMARK stages (markerdetector.cpp:472-476): names via arucohip_stage_name. Returns count. */
 int arucohip_stage_times(arucohip_handle* h, float* ms, int cap);

@@ -238,3 +238,34 @@ def test_gl_modelviews_of_hip_detected_poses(env):
         assert L.arucohip_gl_modelview_n(nopose.ctypes.data_as(C.c_void_p), len(nopose), mvn.ctypes.data_as(C.c_void_p)) == capi.E_INVALID
     finally:
         h.close()
+
+
+def test_threshold_device_clock_span_agrees_with_the_event_interval(env):
+    """arucohip_threshold_exec_ms (first wave in, last wave out by the device's constant-rate clock) against the hipEvent interval
+    of the same launches, one batch at a time — the two ways bench.py times the dominant kernel. 10 % tolerance: the event
+    interval also holds the launch latency and the small reduction kernel."""
+    capi, torch = env["capi"], env["torch"]
+    from aruco_amd import synth
+    n = 256
+    fr, _ = synth.make_stream(n, seed=21, device="cuda")
+    torch.cuda.synchronize()
+    h = capi.Handle(1920, 1080, max_batch=n)
+    try:
+        out = torch.zeros((n, 64 * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            h.detect_batch_device(fr.data_ptr(), n, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        h.batch_status()
+        h.enable_timing(True)
+        for _ in range(4):
+            h.detect_batch_device(fr.data_ptr(), n, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        h.batch_status()
+        ev = h.kernel_times()["threshold_kernel"]
+        ms, launches = h.threshold_exec_ms()
+        h.enable_timing(False)
+        assert launches == 4
+        clk = ms / launches
+        assert 0.1 < clk < 1.0                      # 256 frames: about 0.27 ms
+        assert abs(clk - ev) / ev < 0.10, (clk, ev)
+    finally:
+        h.close()
