@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
 }
 
 // 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram.
-// The wave takes the patch in 8x8-pixel blocks, lane = pixel of the block, four blocks in flight so that the gathers
+// The wave takes the patch in 8x8-pixel blocks, lane = pixel of the block, GQ = 7 blocks (a block row of a 56x56 patch) in flight so that the gathers
 // overlap (round 1 mapped lanes to the 56 pixels of a patch row: for a rotated marker every lane then reads a different
 // image row; round 2: 0.75 -> 0.56 ms per 1024 frames). Every pixel forms exactly the products and sums cv::warpPerspective
 // forms (iM[0]*x + (iM[1]*y + iM[2]) ...).
@@ -226,6 +226,10 @@ __global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
 constexpr int HCOPIES = HCOPIES_N, HPITCH = 65;   // words per copy: 64 (bins 4w .. 4w+3) + 1 so that copies start in different banks
 constexpr int HWCOPIES = HCOPIES / 4, HWPITCH = 257;
 constexpr int HLANES = WAVE / HCOPIES;            // lanes that share a copy
+#ifndef GQ_N
+#define GQ_N 7
+#endif
+constexpr int GQ = GQ_N;                          // 8x8 patch blocks (wave-gathers) in flight
 static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     latency_bound_priority();
@@ -251,11 +255,11 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         // marker crosses 56 image rows, an 8x8 block of the patch covers about 21 x 21 source pixels whatever the rotation.
         const int bxl = lane & 7, byl = lane >> 3;
         const int nb = (ws + 7) >> 3, nblocks = nb * nb;
-        for (int b0 = 0; b0 < nblocks; b0 += 4) {
-            uint8_t v[4];
-            int px[4], py[4];
+        for (int b0 = 0; b0 < nblocks; b0 += GQ) {
+            uint8_t v[GQ];
+            int px[GQ], py[GQ];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < GQ; q++) {
                 const int bi = b0 + q, BY = bi / nb, BX = bi - BY * nb;
                 const int x = BX * 8 + bxl, y = BY * 8 + byl;
                 px[q] = x, py[q] = (bi < nblocks && x < ws && y < ws) ? y : -1;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
                 if (py[q] >= 0 && X >= 0 && X < W && Y >= 0 && Y < H) v[q] = src[(size_t)Y * a.row_stride + X];
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < GQ; q++) {
                 if (py[q] >= 0) {
                     patch[py[q] * ws + px[q]] = v[q];
                     if (bytes)
