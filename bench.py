@@ -189,8 +189,8 @@ def stub_main(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step and GPU")
     ap.add_argument("--frames", type=int, default=1024, help="distinct synthetic frames per GPU (SURVEY.md config 2: N=1024)")
     ap.add_argument("--pose", action="store_true", help="config 3: intrinsics + per-marker solvePnP")
