@@ -265,6 +265,10 @@ __global__ __launch_bounds__(64) void threshold_strip_kernel(ThrArgs a) {
 // rows of prefetch: no ring of horizontal sums), neighbour lanes contribute E / O of their first / last dword through the
 // DPP wave shift, the strip's halo dword keeps its own column sums on the two edge lanes. A lane covers two tile columns.
 // ---------------------------------------------------------------------------------------------
+#ifndef THR_PF_N
+#define THR_PF_N 3
+#endif
+constexpr int THR_PF = THR_PF_N;   // gray rows of prefetch per wave
 constexpr int WSTRIP = 1024;    // pixels per wave and row; strips start on 1-KiB boundaries of the row (a 992-pixel strip with
                                 // two halo lanes instead of halo loads was measured: the misaligned 16-byte accesses cost more)
 constexpr uint32_t SEL02 = 0x0C020C00u, SEL13 = 0x0C030C01u;   // v_perm selectors: bytes (0, 2) / (1, 3) of a dword as u16 pairs
@@ -507,13 +511,13 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes, unsigned l
             int segs;
             if (waves128 >= 512) {
                 segs = (a.height + 127) / 128;
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 128>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
+                hipLaunchKernelGGL((threshold_wide_kernel<R, THR_PF, 128>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             } else if (waves128 * 4 >= 512) {
                 segs = (a.height + 31) / 32;
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 32>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
+                hipLaunchKernelGGL((threshold_wide_kernel<R, THR_PF, 32>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             } else {
                 segs = (a.height + 15) / 16;
-                hipLaunchKernelGGL((threshold_wide_kernel<R, 3, 16>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
+                hipLaunchKernelGGL((threshold_wide_kernel<R, THR_PF, 16>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
             }
             if (a.stamps) hipLaunchKernelGGL(stamp_reduce_kernel, dim3(1), dim3(1024), 0, s, a.stamps, (size_t)strips * segs * nframes, stamp_acc);
             return true;
