@@ -386,7 +386,7 @@ def main():
         achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes of the dominant kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
         # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pipe_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and args.config in (2, 3):     # the committed PMC passes are of the 1080p stream
             try:
@@ -394,6 +394,8 @@ def main():
                 if dom in tj.get("kernels", {}):
                     traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * per_launch
                     traffic_src = "profiles/hbm_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, replayed" % tj.get("tag", "")
+                if args.config == 2:   # all kernels of a batch (the passes are of config 2)
+                    pipe_traffic = sum(k["hbm_bytes_per_frame"] for k in tj["kernels"].values()) * B
             except Exception:
                 traffic = None
         iso_ms = ktimes_iso.get(dom, dom_ms)
@@ -425,7 +427,10 @@ def main():
                          "isolated_launch_ms_device_clock": round(iso_exec_ms / iso_exec_n, 4) if (dom == "threshold_kernel" and iso_exec_n > 0) else None,
                          "frac_isolated": round(ALG_BYTES_PER_FRAME * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
                          "frac_own_bytes": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
-                         "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5)},
+                         "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
+                         # every kernel's PMC bytes (replayed like `traffic`) over the step: how much of the peak the pipeline really moves
+                         "pipeline_traffic_per_step": pipe_traffic,
+                         "frac_pipeline_own_bytes": round(pipe_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 5) if pipe_traffic else None},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_isolated": {k: round(v, 4) for k, v in ktimes_iso.items()},
         }
