@@ -1,0 +1,71 @@
+"""Parameter matrix on synthetic 1080p batches: every combination below runs a 6-frame batch through the HIP path and the
+oracle with the same MarkerDetector settings (threshold block / constant / range, FIXED threshold, corner method, warp size,
+size filter, border distance) and with camera intrinsics + lens distortion, so that the branches of the reference that the
+640x480 goldens do not reach (other block sizes, SUBPIX / HARRIS with distortion, other patch sizes) are compared at the
+bench's frame size. ids / order exact, corners and poses <= 1e-4 relative."""
+import numpy as np
+import pytest
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1]
+DIST = [-0.10, 0.02, 1e-3, -5e-4, 0]
+NF = 6
+
+# (thres_method, p1, p2, range, corner_method, warp_size, min_size, max_size, border_dist)
+CASES = [
+    (1, 7, 7, 0, 3, 56, 0.04, 0.5, 0.025),     # defaults
+    (1, 5, 6, 0, 3, 56, 0.04, 0.5, 0.025),     # 5x5 block
+    (1, 9, 9, 0, 2, 56, 0.04, 0.5, 0.025),     # 9x9 block, SUBPIX (window = 9)
+    (1, 11, 7, 0, 1, 56, 0.04, 0.5, 0.025),    # 11x11 block (narrow threshold kernel), HARRIS
+    (1, 13, 8, 0, 0, 56, 0.04, 0.5, 0.025),    # 13x13 block (32-bit sums), corners as detected
+    (1, 7, 7, 1, 3, 56, 0.04, 0.5, 0.025),     # threshold range 1: three planes per frame
+    (0, 128, 0, 0, 3, 56, 0.04, 0.5, 0.025),   # FIXED threshold
+    (1, 7, 7, 0, 3, 28, 0.04, 0.5, 0.025),     # 28x28 patches
+    (1, 7, 7, 0, 3, 63, 0.04, 0.5, 0.025),     # 63x63 patches (not a multiple of 8)
+    (1, 7, 7, 0, 3, 56, 0.06, 0.2, 0.05),      # tighter size filter, wider border band
+    (1, 7, 7, 0, 2, 56, 0.02, 0.9, 0.0),       # loose size filter, no border band, SUBPIX
+]
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from aruco_amd import capi, synth
+    from oracle import orc
+
+    assert torch.cuda.is_available()
+    capi.load()
+    fr, truth = synth.make_stream(NF, seed=977, device="cuda")
+    torch.cuda.synchronize()
+    return {"capi": capi, "orc": orc, "frames": fr.cpu().numpy(), "truth": truth}
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "m%d_b%d_c%d_r%d_corner%d_ws%d_min%g_max%g_bd%g" % c)
+def test_parameter_matrix_on_1080p_batches(env, case):
+    capi, orc = env["capi"], env["orc"]
+    tm, p1, p2, rng_, cm, ws, mn, mx, bd = case
+    p = capi.default_params()
+    p.thres_method, p.thres_param1, p.thres_param2, p.thres_param1_range = tm, p1, p2, rng_
+    p.corner_method, p.warp_size, p.min_size, p.max_size, p.border_dist = cm, ws, mn, mx, bd
+    h = capi.Handle(1920, 1080, max_batch=NF, params=p)
+    try:
+        got = h.detect_batch_host(env["frames"], K=K, dist=DIST, marker_size=0.05)
+    finally:
+        h.close()
+    o = orc.Oracle(thres_method=tm, thres_p1=p1, thres_p2=p2, thres_range=rng_, corner_method=cm, warp_size=ws, min_size=mn, max_size=mx,
+                   border_dist=bd)
+    found = 0
+    for f in range(NF):
+        ref = o.detect(env["frames"][f], K=K, dist=DIST, marker_size=0.05)
+        assert [int(m["id"]) for m in got[f]] == [m["id"] for m in ref], f
+        for a, b in zip(got[f], ref):
+            ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+            assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4, f          # 1e-4 relative (north_star)
+            assert int(a["has_pose"]) == 1
+            assert rel_err(a["rvec"], b["rvec"]) < 1e-4 and rel_err(a["tvec"], b["tvec"]) < 1e-4, f
+        found += len(ref)
+    if tm == 1 and mx >= 0.5:
+        assert found >= 15 * NF          # the adaptive settings find nearly every rendered marker
