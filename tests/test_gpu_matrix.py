@@ -69,3 +69,56 @@ def test_parameter_matrix_on_1080p_batches(env, case):
         found += len(ref)
     if tm == 1 and mx >= 0.5:
         assert found >= 15 * NF          # the adaptive settings find nearly every rendered marker
+
+
+# (width, height, row stride, x offset, y offset) of a window of the 1080p frames, handed over with that row stride
+GEOMETRIES = [
+    (1283, 727, 1283, 300, 200),     # odd width and stride: byte-wise threshold kernel
+    (1280, 720, 1280, 320, 180),     # 16-byte aligned rows: wide kernel, 2 strips (the second one partial)
+    (1000, 1000, 1024, 400, 40),     # width a multiple of 8 only, padded stride
+    (1920, 1080, 2048, 0, 0),        # full frame with padded rows
+    (1024, 1024, 1024, 500, 30),     # exactly one 1-KiB strip
+    (1040, 600, 1040, 100, 300),     # one strip + 16 pixels
+    (644, 483, 644, 900, 400),       # multiple of 4 only: dword kernel
+]
+
+
+@pytest.mark.parametrize("geo", GEOMETRIES, ids=lambda g: "%dx%d_stride%d" % g[:3])
+def test_frame_geometries(env, geo):
+    """Frames of other sizes, alignments and row strides (windows of the synthetic 1080p frames, device-resident with the given
+    row stride): thresholded image and every marker against the oracle on the same window."""
+    import torch
+    capi, orc = env["capi"], env["orc"]
+    w, hgt, stride, x0, y0 = geo
+    win = np.ascontiguousarray(env["frames"][:3, y0:y0 + hgt, x0:x0 + w])
+    assert win.shape == (3, hgt, w)
+    buf = np.zeros((3, hgt, stride), np.uint8)
+    buf[:, :, :w] = win
+    buf[:, :, w:] = 255 - (np.arange(stride - w, dtype=np.uint8) * 37)[None, None, :] if stride > w else 0   # padding must not matter
+    dev = torch.from_numpy(buf).cuda()
+    out = torch.zeros((3, 64 * 96), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    h = capi.Handle(w, hgt, max_batch=3)
+    try:
+        h.detect_batch_device(dev.data_ptr(), 3, w, hgt, out.data_ptr(), 64, cnt.data_ptr(), K=K, dist=DIST, marker_size=0.05, row_stride=stride,
+                              frame_stride=stride * hgt)
+        h.batch_status()
+        torch.cuda.synchronize()
+        arr = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(3, 64)
+        n = cnt.cpu().numpy()
+        o = orc.Oracle()
+        total = 0
+        for f in range(3):
+            ref = o.detect(win[f], K=K, dist=DIST, marker_size=0.05)
+            assert np.array_equal(h.thresholded(f, (hgt, w)), o.thresholded()), f
+            got = arr[f, :n[f]]
+            assert [int(m["id"]) for m in got] == [m["id"] for m in ref], f
+            for a, b in zip(got, ref):
+                ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+                assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4, f
+                assert rel_err(a["rvec"], b["rvec"]) < 1e-4 and rel_err(a["tvec"], b["tvec"]) < 1e-4, f
+            total += len(ref)
+        assert total > 0
+    finally:
+        h.close()
