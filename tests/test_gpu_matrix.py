@@ -122,3 +122,43 @@ def test_frame_geometries(env, geo):
         assert total > 0
     finally:
         h.close()
+
+
+def test_4k_board_with_harris_and_reprojection_filter(env):
+    """SURVEY §8d config 4, second form: the aruco_test_board configuration (utils/aruco_test_board.cpp:146-149) — HARRIS corner refinement and
+    set_repj_err_thres(1.5) — on 3840x2160 board frames: markers and both board-pose entries (per frame, batched) against the oracle."""
+    import torch
+    from tests.util import load_case
+    from aruco_amd import synth
+    capi, orc = env["capi"], env["orc"]
+    W, H, NB = 3840, 2160, 3
+    _, doc = load_case("board")
+    bc = doc["board_conf"]
+    Kb = np.array(doc["intrinsics"]["K"], np.float32).reshape(3, 3)
+    Kb[0, 0] *= np.float32(W / 640.0); Kb[0, 2] *= np.float32(W / 640.0)
+    Kb[1, 1] *= np.float32(H / 480.0); Kb[1, 2] *= np.float32(H / 480.0)
+    Kf = Kb.reshape(-1)
+    dist = [0.0] * 5
+    frames, _ = synth.make_board_stream(NB, bc["ids"], bc["obj"], Kf, width=W, height=H, seed=31, device="cuda")
+    torch.cuda.synchronize()
+    host = frames.cpu().numpy()
+    p = capi.default_params()
+    p.corner_method = capi.CORNER_HARRIS if hasattr(capi, "CORNER_HARRIS") else 1
+    h = capi.Handle(W, H, max_batch=NB, params=p)
+    try:
+        got = h.detect_batch_host(host)
+        batched = h.board_detect_batch(NB, bc["ids"], bc["obj"], bc["info_type"], Kf, dist, 0.039, repj_err_thres=1.5)
+        o = orc.Oracle(corner_method=1)
+        for f in range(NB):
+            ref = o.detect(host[f])
+            assert [int(m["id"]) for m in got[f]] == [m["id"] for m in ref] and len(ref) >= 20
+            for a, b in zip(got[f], ref):
+                ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+                assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4
+            ob = orc.board_detect(ref, bc["ids"], bc["obj"], bc["info_type"], Kf, dist, 0.039, 1.5, False)
+            one = h.board_detect(got[f], bc["ids"], bc["obj"], bc["info_type"], Kf, dist, 0.039, repj_err_thres=1.5)
+            for bb in (one, batched[f]):
+                assert bb["has_pose"] == ob["has_pose"] == 1
+                assert rel_err(bb["rvec"], ob["rvec"]) < 1e-4 and rel_err(bb["tvec"], ob["tvec"]) < 1e-4
+    finally:
+        h.close()
