@@ -36,6 +36,7 @@ Tuning read_tuning() {
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
+    t.thres_lazy = geti("ARUCOHIP_THRES_BYTES", 0) == 0;
     if (const char* e = getenv("ARUCOHIP_GENS")) {
         for (const char* q = e; *q && t.ngens < 32;) {
             const int v = atoi(q);
@@ -129,6 +130,7 @@ struct arucohip_handle {
     hipStream_t side_stream = nullptr;   // late walker generations (k_contours.hip)
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     hipEvent_t ev_thr = nullptr;         // this worker's threshold kernel has finished (staggers the chunks, see detect_batch)
+    bool thres_bytes = true;             // buf.thres holds the last batch's byte image (else: tiles + buf.thres_edge, expanded on demand)
     hipEvent_t wait_thr = nullptr;       // set by detect_batch: event the next threshold kernel waits for
     int last_chunks = 1, last_per = 0;   // chunks and frames per chunk of the last batch
     // Batches in flight (arucohip_set_pipeline_depth / _submit / _wait): every pipeline lane is a complete worker (own
@@ -240,7 +242,7 @@ static void free_all(arucohip_handle* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (auto& e : h->ev_join)
         if (e) hipEventDestroy(e);
-    hipFree(h->buf.thr_stamps), hipFree(h->buf.thr_acc);
+    hipFree(h->buf.thr_stamps), hipFree(h->buf.thr_acc), hipFree(h->buf.thres_edge);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.trig), hipFree(h->buf.gen_buf), hipFree(h->zero_block), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
     hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
@@ -313,6 +315,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_markers = lim->markers_per_frame;
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
+    ALLOC(b.thres_edge, P * (size_t)(2 * lim->max_width + 2 * lim->max_height));
     {   // timing stamps of the wide threshold kernel: its finest grid is one wave per 1024-px strip and 16 rows
         const size_t waves = (size_t)tile_strips(lim->max_width) * ((lim->max_height + 15) / 16) * F;
         ALLOC(b.thr_stamps, 2 * waves * sizeof(uint64_t));
@@ -710,10 +713,14 @@ static int grow(arucohip_handle* h, uint8_t** buf, size_t* have, size_t need);
 
 // threshold stage of any method into buf.thres / buf.tiles (+ bitmap). CANNY (markerdetector.cpp:667-676) blocks the host while its
 // hysteresis converges.
-static int run_threshold(arucohip_handle* h, hipStream_t s, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp) {
+// want_bytes: the caller reads buf.thres right away (stage entry point, erosion); otherwise the byte image may be left as tiles + border
+// lines (h->thres_bytes says which) and arucohip_get_thresholded expands the plane it is asked for.
+static int run_threshold(arucohip_handle* h, hipStream_t s, const uint8_t* gray_dev, const FrameGeom& g, int nframes, const DetectParams& dp, bool want_bytes) {
     const Buffers& b = h->buf;
+    h->thres_bytes = true;
     if (dp.thres_method != ARUCOHIP_THRES_CANNY) {
-        launch_threshold(s, gray_dev, g, nframes, dp, b);
+        const bool lazy = launch_threshold(s, gray_dev, g, nframes, dp, b, b.tune.thres_lazy && !want_bytes && !h->params.erode);
+        h->thres_bytes = !lazy;
         return ARUCOHIP_OK;
     }
     const size_t ntiles = (size_t)nframes * dp.nthr * ((g.width + 7) / 8) * ((g.height + 7) / 8);
@@ -744,7 +751,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     if (h->wait_thr) HIPCHK(h, hipStreamWaitEvent(s, h->wait_thr, 0));   // threshold kernels of the lanes run one after the other
     MARK(K_THRESHOLD);   // after that wait: the interval is this batch's own threshold kernel
     {
-        const int rc_ = run_threshold(h, s, gray_dev, g, nframes, dp);
+        const int rc_ = run_threshold(h, s, gray_dev, g, nframes, dp, false);
         if (rc_) return rc_;
     }
     if (h->params.erode) {
@@ -1132,6 +1139,12 @@ int arucohip_get_thresholded(arucohip_handle* h0, int frame, uint8_t* dst) {
     HIPCHK(h, hipSetDevice(h->device));
     size_t px = (size_t)h->last_w * h->last_h;
     int plane = frame * h->last_nthr + h->last_nthr / 2;   // thres = thres_images[n_param1 / 2]
+    if (!h->thres_bytes) {   // the batch kept the image as tiles + border lines: rebuild this plane's bytes
+        FrameGeom g;
+        g.width = h->last_w, g.height = h->last_h, g.row_stride = (size_t)h->last_w, g.frame_stride = px;
+        launch_expand_thres(h->stream, g, plane, h->buf);
+        HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres + plane * px, px, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ARUCOHIP_OK;
@@ -1297,7 +1310,7 @@ int arucohip_threshold(arucohip_handle* h, int method, const uint8_t* gray, int 
     if ((rc = stage_frames(h, gray, 1, W, H, row_stride, (size_t)H * row_stride, 0, 1, &gray_dev, &g))) return rc;
     HIPCHK(h, hipMemsetAsync(h->zero_block, 0, h->zero_words * sizeof(uint32_t), h->stream));
     if ((rc = ensure_bits_geometry(h, W, H))) return rc;
-    if ((rc = run_threshold(h, h->stream, gray_dev, g, 1, dp))) return rc;
+    if ((rc = run_threshold(h, h->stream, gray_dev, g, 1, dp, true))) return rc;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(dst, h->buf.thres, (size_t)W * H, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -119,6 +119,7 @@ struct Tuning {
     int ngens = 0;
     int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
+    int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
 };
 Tuning read_tuning();          // capi.hip
@@ -139,6 +140,7 @@ struct Buffers {
     uint32_t* gen_cnt;     // counters of the long-walk generation lists (k_contours.hip), zeroed per batch
     ContourDesc* cdesc;
     short2* pool;
+    uint8_t* thres_edge;    // [P][2 W + 2 H] border lines of the thresholded planes when the byte image is left out (k_threshold.hip)
     uint64_t* thr_stamps;   // timing: per-wave device-clock stamps of the wide threshold kernel [2 * waves]
     uint64_t* thr_acc;      // timing: {clock ticks, launches} accumulated by stamp_reduce_kernel
     int thr_stamp_on;       // stamps are taken (arucohip_enable_timing)
@@ -175,7 +177,8 @@ __device__ __forceinline__ void latency_bound_priority() { __builtin_amdgcn_s_se
 
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_bgr2gray(hipStream_t s, const uint8_t* bgr, size_t row_stride, size_t frame_stride, int width, int height, int nframes, uint8_t* gray);
-void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+bool launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, bool lazy);
+void launch_expand_thres(hipStream_t s, const FrameGeom& g, int plane, const Buffers& b);
 void launch_undist_map(hipStream_t s, int W, int H, const float* K, const float* dist, int ndist, short2* xy, uint16_t* fxy);
 void launch_remap(hipStream_t s, const uint8_t* src, size_t row_stride, size_t frame_stride, int W, int H, int cn, int nframes, const short2* xy,
                   const uint16_t* fxy, uint8_t* dst);

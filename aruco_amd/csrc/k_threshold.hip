@@ -43,6 +43,7 @@ struct ThrArgs {
     uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
     int nstrips;          // 128-tile strips per tile row
     uint64_t* stamps;     // timing only (else null): first / last device-clock reading of every wave of the wide kernel
+    uint8_t* edge;        // lazy byte image (thres == null): the four border lines of every plane [P][2 W + 2 H], see expand_thres_kernel
 };
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -285,7 +286,7 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
     const int ye8 = (ye + 7) & ~7;
     const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
     const int plane = frame * a.nthr + a.t;
-    uint8_t* tdst = a.thres + (size_t)plane * W * H;
+    uint8_t* tdst = a.thres ? a.thres + (size_t)plane * W * H : nullptr;
     uint64_t* bdst = a.tiles + (size_t)plane * a.tnx * a.tny;
 
     const bool out_lane = x < W;
@@ -388,7 +389,17 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
         if (c < ye && out_lane) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 tv = {t4[0], t4[1], t4[2], t4[3]};
-            __builtin_nontemporal_store(tv, (u32x4*)(tdst + (size_t)c * W + xa));
+            if (a.thres) {
+                __builtin_nontemporal_store(tv, (u32x4*)(tdst + (size_t)c * W + xa));
+            } else {
+                // The byte image is not written: the tiles below hold it as bits except for its four border lines (cleared there,
+                // as cv::findContours does), which go to a side array; expand_thres_kernel rebuilds the bytes when they are asked for.
+                uint8_t* e = a.edge + (size_t)plane * (2 * W + 2 * H);
+                if (c == 0) *(u32x4*)(e + xa) = tv;
+                if (c == H - 1) *(u32x4*)(e + W + xa) = tv;
+                if (x == 0) e[2 * W + c] = (uint8_t)(t4[0] & 0xFFu);
+                if (x == W - 16) e[2 * W + H + c] = (uint8_t)(t4[3] >> 24);
+            }
         }
         // ---- binary image for contour purposes, frame cleared: one byte per tile row and tile column
         const bool rs_on = c >= 1 && c <= H - 2;
@@ -474,6 +485,29 @@ __global__ __launch_bounds__(1024) void stamp_reduce_kernel(const uint64_t* __re
     if (threadIdx.x == 0 && smax[0] > smin[0]) acc[0] += smax[0] - smin[0], acc[1] += 1;
 }
 
+// Lazy byte image: one plane of the thresholded image (0 / 255 bytes) from its tiles and its four border lines. A thread per 8 pixels.
+__global__ __launch_bounds__(256) void expand_thres_kernel(const uint64_t* __restrict__ tiles, const uint8_t* __restrict__ edge, int W, int H, int tnx,
+                                                           uint8_t* __restrict__ dst) {
+    const int x8 = 8 * (int)(blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
+    if (x8 >= W) return;
+    const uint32_t bits = (uint32_t)(tiles[(size_t)(y >> 3) * tnx + (x8 >> 3)] >> (8 * (y & 7))) & 0xFFu;
+    for (int j = 0; j < 8 && x8 + j < W; j++) {
+        const int x = x8 + j;
+        uint8_t v = (uint8_t)(((bits >> j) & 1u) * 255u);
+        if (y == 0) v = edge[x];
+        else if (y == H - 1) v = edge[W + x];
+        else if (x == 0) v = edge[2 * W + y];
+        else if (x == W - 1) v = edge[2 * W + H + y];
+        dst[(size_t)y * W + x] = v;
+    }
+}
+
+void launch_expand_thres(hipStream_t s, const FrameGeom& g, int plane, const Buffers& b) {
+    const int W = g.width, H = g.height, tnx = tiles_x(W), tny = tiles_y(H);
+    hipLaunchKernelGGL(expand_thres_kernel, dim3((W / 8 + 256) / 256, H), dim3(256), 0, s, b.tiles + (size_t)plane * tnx * tny,
+                       b.thres_edge + (size_t)plane * (2 * W + 2 * H), W, H, tnx, b.thres + (size_t)plane * W * H);
+}
+
 // the non-empty-tile bitmap for the paths whose kernel does not write it (narrow / FIXED / caller-supplied binary image): one
 // wave per (strip, tile row, plane) reads the strip's 128 tiles
 __global__ __launch_bounds__(64) void tile_bitmap_kernel(const uint64_t* __restrict__ tiles, uint64_t* __restrict__ tile_bits, int tnx, int tny, int nstrips) {
@@ -539,15 +573,28 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width), a.wide_ok = b.tune.threshold_wide;
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.stamps = b.thr_stamp_on ? b.thr_stamps : nullptr;
+    a.edge = nullptr;
     a.fast = ((g.width | (int)(g.row_stride & 3) | (int)(g.frame_stride & 3) | (int)((uintptr_t)gray & 3)) & 3) == 0;
     a.fast16 = g.width >= 16 && ((g.width | (int)(g.row_stride & 15) | (int)(g.frame_stride & 15) | (int)((uintptr_t)gray & 15) | (int)((uintptr_t)b.thres & 15)) & 15) == 0;
 }
 
-void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+// lazy: the caller does not need the byte image now. Returns true if it was left out (every plane ran the 16-pixel-per-lane kernel,
+// which keeps the border lines instead: launch_expand_thres rebuilds a plane on demand).
+bool launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, bool lazy) {
     bool bitmap_done = true;
+    if (lazy) {   // all planes or none
+        ThrArgs a;
+        fill_args(a, gray, g, b, p.nthr, 0);
+        lazy = p.thres_method == ARUCOHIP_THRES_ADPT && a.fast16 && a.wide_ok && b.thres_edge != nullptr;
+        for (int t = 0; t < p.nthr && lazy; t++) {
+            const long n = (long)p.block[t] * p.block[t];
+            lazy = p.block[t] / 2 >= 1 && p.block[t] / 2 <= 4 && (long)(256 + abs(p.idelta)) * n + n / 2 < 32768;
+        }
+    }
     for (int t = 0; t < p.nthr; t++) {
         ThrArgs a;
         fill_args(a, gray, g, b, p.nthr, t);
+        if (lazy) a.thres = nullptr, a.edge = b.thres_edge;
         if (p.thres_method == ARUCOHIP_THRES_FIXED) {
             a.idelta = (int)floor(p.p1[t]);
             dim3 grid((g.width + STRIP - 1) / STRIP, (g.height + SEG - 1) / SEG, nframes);
@@ -578,6 +625,7 @@ void launch_threshold(hipStream_t s, const uint8_t* gray, const FrameGeom& g, in
         }
     }
     if (!bitmap_done) launch_tile_bitmap(s, g, nframes * p.nthr, b);
+    return lazy;
 }
 
 // Optional erosion (north_star; off by default, no reference counterpart in this snapshot): 3x3 minimum of the thresholded

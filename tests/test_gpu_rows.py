@@ -181,3 +181,33 @@ def ndimage_like_blur(a):
     for _ in range(6):
         a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5
     return (a - a.min()) / (a.max() - a.min())
+
+
+def test_thresholded_image_kept_as_tiles_equals_the_byte_image(env, monkeypatch):
+    """getThresholdedImage (src/markerdetector.h:183) after a batch: by default the 16-pixel-per-lane threshold kernel keeps the image as
+    bit tiles + its four border lines and arucohip_get_thresholded expands the plane asked for; ARUCOHIP_THRES_BYTES=1 writes the bytes in
+    the hot path. Both equal cv::adaptiveThreshold's restatement on every frame, borders included, also with a threshold range."""
+    capi, orc, torch = env["capi"], env["orc"], env["torch"]
+    from aruco_amd import synth
+    fr, _ = synth.make_stream(4, seed=77, device="cuda")
+    torch.cuda.synchronize()
+    frames = fr.cpu().numpy()
+    frames[1, 0, :] = 0; frames[1, -1, :] = 255; frames[1, :, 0] = 0; frames[1, :, -1] = 255     # something on the border lines
+    frames[2, 0, ::2] = 0; frames[2, :, -1][::3] = 0
+    for rng_ in (0, 1):
+        p = capi.default_params()
+        p.thres_param1_range = rng_
+        got = {}
+        for eager in ("0", "1"):
+            monkeypatch.setenv("ARUCOHIP_THRES_BYTES", eager)
+            h = capi.Handle(1920, 1080, max_batch=4, params=p)
+            try:
+                markers = h.detect_batch_host(frames)
+                got[eager] = ([m.tobytes() for m in markers], [h.thresholded(f, (1080, 1920)) for f in range(4)])
+            finally:
+                h.close()
+        assert got["0"][0] == got["1"][0]
+        for f in range(4):
+            assert np.array_equal(got["0"][1][f], got["1"][1][f]), (rng_, f)
+            ref = orc.adaptive_threshold(frames[f], 7, 7.0)       # the middle plane of the range is the configured block size
+            assert np.array_equal(got["0"][1][f], ref), (rng_, f)
