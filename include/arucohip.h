@@ -211,7 +211,9 @@ int arucohip_detect_batch_submit(arucohip_handle* h, const uint8_t* frames, int 
 int arucohip_detect_batch_wait(arucohip_handle* h, int ticket);
 
 /* MarkerDetector::getThresholdedImage (markerdetector.h:183): thresholded image of frame `frame` of the last call
- * (the middle one when thres_param1_range > 0), copied to host `dst` (width*height bytes, tightly packed). */
+ * (the middle one when thres_param1_range > 0), copied to host `dst` (width*height bytes, tightly packed). The hot path keeps the image
+ * as bit tiles plus its four border lines (what cv::findContours works on); this call expands the requested plane to the reference's
+ * 0 / 255 bytes. ARUCOHIP_THRES_BYTES=1 (environment, read at handle creation) writes the bytes during detection instead. */
 int arucohip_get_thresholded(arucohip_handle* h, int frame, uint8_t* dst);
 /* MarkerDetector::getCandidates (markerdetector.h:266): quads that were rectangles but not markers. quads: cap*8 floats. */
 int arucohip_get_candidates(arucohip_handle* h, int frame, float* quads, int cap, int* n);
