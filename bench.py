@@ -408,7 +408,9 @@ def main():
                                     + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
                                    + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else ""),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
-                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "frames sharded 1 stream/GPU"
+                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth,
+                       "thresholded_image": "written in the hot path" if os.environ.get("ARUCOHIP_THRES_BYTES", "0") not in ("", "0") else
+                       "kept as bit tiles + border lines, bytes on request (ARUCOHIP_THRES_BYTES=1 writes them in the hot path)", "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "frames sharded 1 stream/GPU"
                        + (", RCCL gather of marker blocks per step" if world > 1 else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
