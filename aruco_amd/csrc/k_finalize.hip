@@ -161,13 +161,17 @@ void launch_marker_pose(hipStream_t s, arucohip_marker_t* markers, int n, const 
     hipLaunchKernelGGL(pose_kernel, dim3((n + 15) / 16), dim3(64), 0, s, markers, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, n, cam);
 }
 
-// generic planar PnP over npts correspondences (board pose): a single lane, everything in private memory
-__global__ void pnp_points_kernel(const float* obj, const float* img, int npts, CamModel cam, double* rt, int* ok_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// generic planar PnP over npts correspondences (board pose of one arucohip_board_detect call): one wavefront, the lanes share the
+// points (wave sums for the homography and J^T J) like board_pose_kernel. A single lane took 1.7 ms for the 96 points of the
+// reference's board still (ArucoPerf.Board), more than the rest of the call.
+__global__ __launch_bounds__(64) void pnp_points_kernel(const float* obj, const float* img, int npts, CamModel cam, double* rt, int* ok_out) {
+    if (blockIdx.x != 0) return;
     double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
-    bool ok = solve_pnp_planar(obj, img, npts, cam, r, t);
-    for (int k = 0; k < 3; k++) rt[k] = r[k], rt[3 + k] = t[k];
-    *ok_out = ok ? 1 : 0;
+    const bool ok = solve_pnp_planar_wave<64>(obj, img, npts, cam, r, t, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; k++) rt[k] = r[k], rt[3 + k] = t[k];
+        *ok_out = ok ? 1 : 0;
+    }
 }
 
 void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out) {

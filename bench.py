@@ -78,41 +78,93 @@ def cpu_baseline(frames_host, seconds_single=8.0, seconds_multi=12.0):
 
 
 def latency_leg(capi, frame_1080p, runs=1000, cpu_seconds=1.5):
-    """The reference's own performance methodology (test/perf_tests.cpp:31-56): detect() on a single gray still held in host
-    memory, mean wall-clock ms over `runs` calls — arucohip_detect including the H2D of the frame and the D2H of the markers.
-    The three 640x480 stills the reference's tests use plus one of the bench's 1080p frames; both contour pipelines of the
-    library (per-candidate walkers, the default, and waypoint segments); the CPU restatement's ms beside it (1 thread)."""
+    """The reference's own performance tests (test/perf_tests.cpp: ArucoPerf.Single :31-56, .Board :58-86, .Multi :88-119,
+    .HRM_Single :160-199, .GL_Conversion :121-158) on the same stills with the same settings: one gray frame in host memory per
+    call, camera parameters given (poses are part of the call), BoardDetector::detect after it for Board / Multi, the d4x4_100
+    dictionary and the test's detector settings for HRM_Single; mean wall-clock ms over `runs` calls, H2D of the frame and D2H of
+    the results included. Both contour pipelines of the library (per-candidate walkers, waypoint segments: the default for single
+    small frames) and the CPU restatement's ms beside them (1 thread). Plus one of the bench's 1080p frames (no pose)."""
     import numpy as np
 
     from aruco_amd.fixtures import load_case
     from oracle import orc
 
-    stills = [(n, load_case(n)[0]) for n in ("single", "board", "chessboard")] + [("synthetic_1080p", np.ascontiguousarray(frame_1080p))]
-    out = {"method": "mean ms of %d arucohip_detect calls on one host frame (perf_tests.cpp:31-56), cpu = oracle restatement, 1 thread" % runs}
-    o = orc.Oracle()
-    for name, g in stills:
+    out = {"method": "mean ms of %d calls on one host frame as in test/perf_tests.cpp (detect with camera parameters; + BoardDetector::detect for "
+                     "board / chessboard; HRM settings for hrm), cpu = oracle restatement, 1 thread" % runs}
+    cases = [("single", 1.0), ("board", 1.0), ("chessboard", 1.0), ("hrm", None), ("synthetic_1080p", None)]
+    for name, msize in cases:
+        if name == "synthetic_1080p":
+            g, doc = np.ascontiguousarray(frame_1080p), {}
+        else:
+            g, doc = load_case(name)
+        intr = doc.get("intrinsics")
+        K, dist = (intr["K"], intr["dist"]) if intr else (None, None)
+        st, dic, bc = doc.get("settings"), doc.get("dictionary"), doc.get("board_conf")
+        if st:
+            msize = st["marker_size"]
+        if msize is None:
+            msize = -1.0
+        p = capi.default_params()
+        okw = {}
+        if st:   # core_tests.cpp:325-330 / perf_tests.cpp:172-177
+            p.thres_param1, p.thres_param2, p.min_size, p.max_size, p.warp_size = st["thres_param1"], st["thres_param2"], st["min_size"], st["max_size"], st["warp_size"]
+            okw = dict(thres_p1=st["thres_param1"], thres_p2=st["thres_param2"], min_size=st["min_size"], max_size=st["max_size"], warp_size=st["warp_size"])
         row = {}
         for mode in ("walkers", "segments"):
             os.environ["ARUCOHIP_CONTOURS"] = mode
-            h = capi.Handle(g.shape[1], g.shape[0], max_batch=1)
+            h = capi.Handle(g.shape[1], g.shape[0], max_batch=1, params=p)
             try:
+                if dic:
+                    h.set_dictionary(dic["markers"], dic["tau0"])
+
+                def call():
+                    m = h.detect(g, K=K, dist=dist, marker_size=msize)
+                    if bc:
+                        h.board_detect(m, bc["ids"], bc["obj"], bc["info_type"], K=K, dist=dist, marker_size=msize)
+                    return m
                 for _ in range(20):
-                    got = h.detect(g)
+                    got = call()
                 t0 = time.perf_counter()
                 for _ in range(runs):
-                    h.detect(g)
+                    call()
                 row[mode + "_ms"] = round((time.perf_counter() - t0) / runs * 1e3, 4)
                 row["markers"] = len(got)
             finally:
                 h.close()
         os.environ.pop("ARUCOHIP_CONTOURS", None)
-        o.detect_raw(g)
+        o = orc.Oracle(**okw)
+        if dic:
+            o.set_hrm_dictionary(dic["markers"], dic["tau0"])
+
+        def cpu_call():
+            m = o.detect(g, K=K, dist=dist, marker_size=msize) if K is not None else o.detect_raw(g)
+            if bc:
+                orc.board_detect(m, bc["ids"], bc["obj"], bc["info_type"], K, dist, msize)
+        cpu_call()
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < cpu_seconds:
-            o.detect_raw(g)
+            cpu_call()
             n += 1
         row["cpu_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
         out[name] = row
+    # ArucoPerf.GL_Conversion: projection matrix + the board's and every marker's model-view matrix from their poses (host arithmetic)
+    g, doc = load_case("board")
+    intr, bc = doc["intrinsics"], doc["board_conf"]
+    h = capi.Handle(g.shape[1], g.shape[0], max_batch=1)
+    try:
+        m = h.detect(g, K=intr["K"], dist=intr["dist"], marker_size=1.0)
+        b = h.board_detect(m, bc["ids"], bc["obj"], bc["info_type"], K=intr["K"], dist=intr["dist"], marker_size=1.0)
+    finally:
+        h.close()
+    size = (g.shape[1], g.shape[0])
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        capi.gl_projection(intr["K"], size, size, 0.5, 10)
+        capi.gl_modelview(b["rvec"], b["tvec"])
+        for mk in m:
+            capi.gl_modelview(mk["rvec"], mk["tvec"])
+    out["gl_conversion"] = {"ms": round((time.perf_counter() - t0) / runs * 1e3, 4), "matrices": len(m) + 2,
+                            "note": "ctypes call per matrix; the arithmetic is arucohip_gl_projection / arucohip_gl_modelview on the host"}
     return out
 
 
