@@ -292,15 +292,28 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
                 atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
         }
     };
-    // one queued tile per lane
-    auto evaluate = [&](bool live, uint32_t id) {
+    // one queued tile per lane: the tile and its five neighbours (loads only; two sets are put in flight before either is used)
+    struct TileSet {
+        uint64_t T, L, U, UL, UR, Rt;
+        int tx, ty;
+    };
+    auto fetch = [&](bool live, uint32_t id) -> TileSet {
+        TileSet q;
+        q.ty = (int)(id >> 16), q.tx = (int)(id & 0xFFFFu);
+        q.T = q.L = q.U = q.UL = q.UR = q.Rt = 0ull;
         if (live) {
-            const int ty = (int)(id >> 16), tx = (int)(id & 0xFFFFu);
-            const uint64_t* t = tiles + (size_t)ty * a.tnx + tx;
-            const uint64_t T = t[0];
-            const uint64_t L = tx > 0 ? t[-1] : 0ull;
-            const uint64_t U = ty > 0 ? t[-a.tnx] : 0ull, UL = (ty > 0 && tx > 0) ? t[-a.tnx - 1] : 0ull, UR = ty > 0 ? t[-a.tnx + 1] : 0ull;
-            const uint64_t Rt = t[1];
+            const uint64_t* t = tiles + (size_t)q.ty * a.tnx + q.tx;
+            q.T = t[0];
+            q.L = q.tx > 0 ? t[-1] : 0ull;
+            q.U = q.ty > 0 ? t[-a.tnx] : 0ull, q.UL = (q.ty > 0 && q.tx > 0) ? t[-a.tnx - 1] : 0ull, q.UR = q.ty > 0 ? t[-a.tnx + 1] : 0ull;
+            q.Rt = t[1];
+        }
+        return q;
+    };
+    auto evaluate = [&](bool live, const TileSet& q) {
+        if (live) {
+            const int ty = q.ty, tx = q.tx;
+            const uint64_t T = q.T, L = q.L, U = q.U, UL = q.UL, UR = q.UR, Rt = q.Rt;
             const uint64_t Wn = ((T << 1) & ~COL0) | ((L >> 7) & COL0);
             const uint64_t N = (T << 8) | (U >> 56), NLt = (L << 8) | (UL >> 56), NRt = (Rt << 8) | (UR >> 56);
             const uint64_t NW = ((N << 1) & ~COL0) | ((NLt >> 7) & COL0);
@@ -315,12 +328,12 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
-                const int q = b >> 3, j = b & 7;
+                const int qr = b >> 3, j = b & 7;
                 const uint32_t kind = (uint32_t)(hole >> b) & 1u;
-                const uint32_t mid = ((((uint32_t)(T >> (8 * q)) & 0xFFu) | (((uint32_t)(Rt >> (8 * q)) & 0xFFu) << 8)) >> j);
-                const uint32_t up = ((((uint32_t)(N >> (8 * q)) & 0xFFu) | (((uint32_t)(NRt >> (8 * q)) & 0xFFu) << 8)) >> j);
+                const uint32_t mid = ((((uint32_t)(T >> (8 * qr)) & 0xFFu) | (((uint32_t)(Rt >> (8 * qr)) & 0xFFu) << 8)) >> j);
+                const uint32_t up = ((((uint32_t)(N >> (8 * qr)) & 0xFFu) | (((uint32_t)(NRt >> (8 * qr)) & 0xFFu) << 8)) >> j);
                 const int avail = 16 - j;
-                const uint32_t pos = base + ((uint32_t)q << 16) + (uint32_t)j;
+                const uint32_t pos = base + ((uint32_t)qr << 16) + (uint32_t)j;
                 const uint32_t runbits = (kind ? mid : ~mid) | (1u << avail);
                 const int Lr = __builtin_ctz(runbits);
                 const int hi = kind ? min(Lr - 1, avail - 1) : min(Lr, avail - 1);
@@ -334,13 +347,25 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
         if (max(s_n[0], s_n[1]) > CS_CAP - 64) flush();   // wave-uniform: room for another round's typical yield
     };
 
+    // The wave's tile rows are ty = blockIdx.x, + gridDim.x, ...; the bitmap words of a row and of the row above it (2 * nstrips each)
+    // are one load by 4 * nstrips lanes, issued one row ahead; the strips read them with v_readlane.
+    const int nw = 2 * a.nstrips;                       // words per tile row; 2 * nw <= 64 (tile_strips() <= 16 for the widths a handle accepts)
+    auto row_words = [&](int ty) -> uint64_t {
+        const int which = lane / nw, idx = lane - which * nw, row = ty - which;
+        return (ty < nty && which < 2 && row >= 0) ? bits[(size_t)row * nw + idx] : 0ull;
+    };
+    auto word_of = [&](uint64_t v, int l) -> uint64_t {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
+    };
     uint32_t qn = 0;   // queued tiles (wave-uniform)
+    uint64_t nextw = row_words(blockIdx.x);
     for (int ty = blockIdx.x; ty < nty; ty += gridDim.x) {
+        const uint64_t curw = nextw;
+        nextw = row_words(ty + gridDim.x);
         for (int st = 0; st < a.nstrips; st++) {
-            const uint64_t* w = bits + (size_t)ty * (2 * a.nstrips) + 2 * st;
-            const uint64_t A = w[0], Bm = w[1];
-            const uint64_t UA = ty > 0 ? w[-2 * a.nstrips] : 0ull, UB = ty > 0 ? w[-2 * a.nstrips + 1] : 0ull;
-            const uint64_t carry = st > 0 ? (w[-1] >> 63) : 0ull;          // the previous strip's last (odd) tile
+            const uint64_t A = word_of(curw, 2 * st), Bm = word_of(curw, 2 * st + 1);
+            const uint64_t UA = word_of(curw, nw + 2 * st), UB = word_of(curw, nw + 2 * st + 1);
+            const uint64_t carry = st > 0 ? (word_of(curw, 2 * st - 1) >> 63) : 0ull;          // the previous strip's last (odd) tile
             // a tile can hold a start if it, its left or its upper neighbour holds a pixel
             const uint64_t needA = A | (Bm << 1) | carry | UA, needB = Bm | A | UB;
 #pragma unroll
@@ -353,21 +378,23 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
                     if (act) s_q[qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)ty << 16) | (uint32_t)tx;
                     qn += (uint32_t)__popcll(bal);
                     __syncthreads();
-                    if (qn >= 128) {   // keep room for the next 64 joins
-                        while (qn >= 64) {
-                            qn -= 64;
-                            evaluate(true, s_q[qn + lane]);
-                        }
+                    if (qn >= 128) {   // keep room for the next 64 joins; two rounds' loads are in flight together
+                        qn -= 128;
+                        const TileSet q0 = fetch(true, s_q[qn + 64 + lane]), q1 = fetch(true, s_q[qn + lane]);
+                        evaluate(true, q0);
+                        evaluate(true, q1);
                     }
                 }
             }
         }
     }
-    while (qn >= 64) {
-        qn -= 64;
-        evaluate(true, s_q[qn + lane]);
+    {
+        const bool l0 = qn >= 64 ? true : (uint32_t)lane < qn;
+        const bool l1 = qn >= 64 && (uint32_t)lane < qn - 64;
+        const TileSet q0 = fetch(l0, l0 ? s_q[lane] : 0u), q1 = fetch(l1, l1 ? s_q[64 + lane] : 0u);
+        if (qn > 0) evaluate(l0, q0);
+        if (qn > 64) evaluate(l1, q1);
     }
-    if (qn > 0) evaluate((uint32_t)lane < qn, (uint32_t)lane < qn ? s_q[lane] : 0u);
     flush();
 }
 
