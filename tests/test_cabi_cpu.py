@@ -76,3 +76,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
             txt = open(os.path.join(csrc, name)).read()
             assert "orc.h" not in txt and "liborc" not in txt, name
     importlib.reload(capi)   # leave the module in its normal state for the other tests
+
+
+def test_headers_are_valid_c99_and_cxx11():
+    """The boundary is a C ABI: include/arucohip.h must compile as plain C99 (a cgo / ctypes / C caller includes it) and as C++11, and
+    the header-only shim as C++11 (the reference's language level), all warning-free with -Wall -Wextra."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    runs = [["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "arucohip.h")],
+            ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", os.path.join(inc, "arucohip.h")],
+            ["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", inc, "-include", os.path.join(inc, "aruco_hip_shim.hpp"), "-x", "c++", os.devnull]]
+    for cmd in runs:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0 and "warning" not in r.stderr, (cmd, r.stderr[-2000:])
