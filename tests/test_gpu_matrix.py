@@ -162,3 +162,38 @@ def test_4k_board_with_harris_and_reprojection_filter(env):
                 assert rel_err(bb["rvec"], ob["rvec"]) < 1e-4 and rel_err(bb["tvec"], ob["tvec"]) < 1e-4
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("shape", [(96, 8192), (72, 16368), (4096, 48), (40, 4112)], ids=lambda s: "%dx%d" % (s[1], s[0]))
+def test_extreme_aspect_frames(env, shape):
+    """Very wide and very tall frames (up to the 14-bit coordinate limit; 8 and 16 strips of the non-empty-tile bitmap, whose words one
+    wave-load fetches per tile row): thresholded image and every kept border against the oracle's sequential scan."""
+    capi, orc = env["capi"], env["orc"]
+    hgt, wid = shape
+    rng = np.random.RandomState(hgt * 7 + wid)
+    a = rng.randn(hgt // 6 + 2, wid // 6 + 2)
+    a = np.kron(a, np.ones((6, 6)))[:hgt, :wid]
+    for _ in range(2):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5
+    g = np.clip(np.where(a > 0, 190, 70) + rng.randint(-3, 4, size=a.shape), 0, 255).astype(np.uint8)
+    p = capi.default_params()
+    p.min_size, p.max_size = 0.002, 0.9
+    import ctypes as C
+    lim = capi.Limits()
+    capi.load().arucohip_default_limits(C.byref(lim), wid, hgt, 1)
+    lim.points_per_frame *= 8                      # a dense texture keeps far more border points than a camera frame of this area
+    lim.contours_per_frame *= 4
+    h = capi.Handle(wid, hgt, max_batch=1, params=p, limits=lim)
+    try:
+        h.detect(g)
+        thr = orc.adaptive_threshold(g, 7, 7.0)
+        assert np.array_equal(h.thresholded(0, g.shape), thr)
+        lo = int(np.float32(0.002) * np.float32(max(wid, hgt)) * np.float32(4))
+        hi = int(np.float32(0.9) * np.float32(max(wid, hgt)) * np.float32(4))
+        ref = [c for c in orc.find_contours(thr) if lo < len(c["pts"]) < hi]
+        got = h.debug_contours(0)
+        assert len(ref) > 20 and len(got) == len(ref)
+        for x, y in zip(got, ref):
+            assert x["hole"] == y["hole"] and np.array_equal(x["pts"], y["pts"])
+    finally:
+        h.close()
