@@ -197,3 +197,57 @@ def test_extreme_aspect_frames(env, shape):
             assert x["hole"] == y["hole"] and np.array_equal(x["pts"], y["pts"])
     finally:
         h.close()
+
+
+def test_degenerate_frames(env):
+    """Constant, checkered and the smallest frames the library takes (32 pixels in a dimension, include/arucohip.h), a frame below that and
+    an empty batch: nothing is found, nothing faults, the thresholded image still equals the restatement."""
+    import torch
+    capi, orc = env["capi"], env["orc"]
+    rng = np.random.RandomState(2)
+    frames = [np.zeros((480, 640), np.uint8), np.full((480, 640), 255, np.uint8), (np.indices((480, 640)).sum(0) % 2 * 255).astype(np.uint8),
+              np.zeros((32, 32), np.uint8), rng.randint(0, 256, (32, 32)).astype(np.uint8), rng.randint(0, 256, (33, 47)).astype(np.uint8),
+              rng.randint(0, 256, (1040, 32)).astype(np.uint8), rng.randint(0, 256, (32, 1040)).astype(np.uint8)]
+    import ctypes as C
+    for i, g in enumerate(frames):
+        hgt, wid = g.shape
+        lim = capi.Limits()
+        capi.load().arucohip_default_limits(C.byref(lim), wid, hgt, 2)
+        if i == 2:
+            # every second pixel of the checkerboard is a border of its own: 150 k start candidates. The default lists report that
+            # (the shim doubles them and detects again); sized for it the frame goes through
+            h = capi.Handle(wid, hgt, max_batch=2)
+            try:
+                with pytest.raises(capi.ArucoHipError) as e:
+                    h.detect(g)
+                assert e.value.code == capi.E_OVERFLOW
+            finally:
+                h.close()
+            lim.triggers_per_frame = 400000
+        h = capi.Handle(wid, hgt, max_batch=2, limits=lim)
+        try:
+            got = h.detect(g)
+            ref = orc.Oracle().detect(g)
+            assert [int(m["id"]) for m in got] == [m["id"] for m in ref]
+            assert np.array_equal(h.thresholded(0, g.shape), orc.adaptive_threshold(g, 7, 7.0)), g.shape
+            both = h.detect_batch_host(np.stack([g, g]))
+            assert len(both) == 2 and all(len(b) == len(ref) for b in both)
+        finally:
+            h.close()
+    h = capi.Handle(640, 480, max_batch=4)
+    try:
+        out = torch.zeros((1, 64 * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        fr = torch.zeros((1, 480, 640), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        # zero frames: either refused as an invalid argument or a no-op; never a fault
+        try:
+            h.detect_batch_device(fr.data_ptr(), 0, 640, 480, out.data_ptr(), 64, cnt.data_ptr())
+        except capi.ArucoHipError as e:
+            assert e.code == capi.E_INVALID
+        with pytest.raises(capi.ArucoHipError) as e:                         # below 32 pixels in a dimension: refused, not a fault
+            h.detect(np.zeros((17, 9), np.uint8))
+        assert e.value.code == capi.E_INVALID
+        assert len(h.detect(np.full((480, 640), 128, np.uint8))) == 0        # the handle is still usable
+    finally:
+        h.close()
