@@ -702,7 +702,7 @@ static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, 
         launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
         launch_segments(h->stream, g, nframes * dp.nthr, dp, h->buf);
     } else {
-        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
+        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf, dp.min_contour);
         run_walkers_and_quads(h, h->stream, g, nframes, dp);
     }
     if (h->buf.seg_mode) launch_contour_quads(h->stream, g, nframes, dp, h->buf);
@@ -770,7 +770,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b);
     } else {
-        launch_start_candidates(s, g, nframes * dp.nthr, b);
+        launch_start_candidates(s, g, nframes * dp.nthr, b, dp.min_contour);
         MARK(K_WALKERS);
         // walkers; their late generations run on the side stream under the first quad pass (the contour_quad mark sits at the fork)
         WalkFork fk{b.tune.walk_fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};

@@ -186,7 +186,7 @@ int launch_canny(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nfr
 void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);
 void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
-void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
+void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, int min_contour = 0);
 struct WalkFork {
     hipStream_t side;            // stream of the late walker generations (nullptr: everything on the main stream)
     hipEvent_t forked, joined;

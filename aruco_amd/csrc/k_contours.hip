@@ -242,6 +242,7 @@ struct SparseArgs {
     uint32_t* trig_cnt;
     uint32_t* counters;
     uint32_t cap_trig;
+    int drop_single;   // the size filter keeps no 1-point border (min contour >= 1): isolated pixels are not worth a start candidate
 };
 
 __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
@@ -321,8 +322,16 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
             const int jmax = a.width - 2 - 8 * tx, imax = a.height - 2 - 8 * ty;
             const uint64_t colm = (jmax >= 7 ? 0xFFull : (jmax < 0 ? 0ull : ((1ull << (jmax + 1)) - 1ull))) * COL0;
             const uint64_t rowm = imax >= 7 ? ~0ull : (imax < 0 ? 0ull : ((1ull << (8 * (imax + 1))) - 1ull));
-            const uint64_t outer = T & ~(Wn | NW | N | NE);
+            uint64_t outer = T & ~(Wn | NW | N | NE);
             const uint64_t hole = ~T & Wn & N & colm & rowm;
+            if (a.drop_single) {
+                // An outer start with no set neighbour at all is a border of one point, which the size filter drops: in noisy frames
+                // these are a large share of the candidates and each would cost the walker a block load. Rows 0..6 of the tile see
+                // their lower neighbours inside T / L / Rt (row 7 would need the tiles below and stays a candidate).
+                const uint64_t E = ((T >> 1) & ~COL7) | ((Rt << 7) & COL7);
+                const uint64_t lower = (T >> 8) | (Wn >> 8) | (E >> 8);            // S, SW, SE of rows 0..6
+                outer &= ~(~(E | lower) & 0x00FFFFFFFFFFFFFFull);
+            }
             const uint32_t base = ((uint32_t)(8 * ty) << 16) | (uint32_t)(8 * tx);
             uint64_t m = outer | hole;
             while (m) {
@@ -398,9 +407,10 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
     flush();
 }
 
-void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b) {
+void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, int min_contour) {
     if (!b.seg_mode && b.tune.cand_sparse) {
         SparseArgs a;
+        a.drop_single = min_contour >= 1;
         a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.nstrips = tile_strips(g.width);
         a.width = g.width, a.height = g.height, a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.counters = b.counters, a.cap_trig = b.cap_trig;
         const int nty = a.tny - 1;
