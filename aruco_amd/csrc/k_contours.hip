@@ -894,6 +894,7 @@ struct QuadArgs {
     int cap_quads, nthr;
     int width, height;
     int pass;
+    int qblocks, nplanes;   // workgroups per plane, planes
 };
 
 // One border -> at most one quad. P holds the border's points: LDS (LDSP, up to QP_LDS points) or the border's own pool range.
@@ -1112,12 +1113,16 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
     __shared__ int s_outn;
-    const int plane = blockIdx.y;
+    // 1-D grid dealt round-robin over the 8 XCDs: all workgroups of a plane land on one XCD, whose L2 then serves the plane's tiles,
+    // descriptors and checkpoints to all of them (same unpacking as walker_kernel)
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int chunk = rest % a.qblocks, plane = (rest / a.qblocks) * 8 + xcd;
+    if (plane >= a.nplanes) return;
     // pass 0: all borders; pass 1: those that existed when the late walker generations were forked; pass 2: the rest
     const uint32_t nall = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
     const uint32_t nsnap = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_SNAP], a.cap_cdesc);
     const uint32_t lo = a.pass == 2 ? nsnap : 0u, ncd = a.pass == 1 ? nsnap : nall;
-    for (uint32_t cslot = lo + blockIdx.x; cslot < ncd; cslot += gridDim.x) {
+    for (uint32_t cslot = lo + (uint32_t)chunk; cslot < ncd; cslot += (uint32_t)a.qblocks) {
         const uint32_t ci = (uint32_t)plane * a.cap_cdesc + cslot;
         const ContourDesc cd = a.cdesc[ci];
         __syncthreads();
@@ -1136,7 +1141,9 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
     const int qb = b.tune.quad_blocks;
-    hipLaunchKernelGGL(contour_quad_kernel, dim3(pass == 2 ? std::max(1, qb / 2) : qb, nframes * p.nthr), dim3(64), 0, s, a);
+    a.qblocks = pass == 2 ? std::max(1, qb / 2) : qb, a.nplanes = nframes * p.nthr;
+    const int planes8 = ((a.nplanes + 7) / 8) * 8;
+    hipLaunchKernelGGL(contour_quad_kernel, dim3(planes8 * a.qblocks), dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

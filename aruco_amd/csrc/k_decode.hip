@@ -229,6 +229,10 @@ constexpr int HLANES = WAVE / HCOPIES;            // lanes that share a copy
 #ifndef GQ_N
 #define GQ_N 7
 #endif
+#ifndef XCD_RUN_N
+#define XCD_RUN_N 48
+#endif
+constexpr uint32_t XCD_RUN = XCD_RUN_N;           // consecutive candidates per XCD in warp_hist_kernel (1: plain round-robin)
 constexpr int GQ = GQ_N;                          // 8x8 patch blocks (wave-gathers) in flight
 static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
@@ -238,7 +242,17 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const int lane = threadIdx.x;
     const int W = a.width, H = a.height;
-    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+    // Workgroups are dealt round-robin over the 8 XCDs. The candidate list is ordered by frame, and the candidates of a marker (its border, the
+    // outline of its quiet zone) sample the same pixels: XCD_RUN consecutive list entries go to one XCD, so that its L2 serves the second
+    // candidate's lines instead of HBM.
+    const uint32_t nslots = ((n + 8 * XCD_RUN - 1) / (8 * XCD_RUN)) * (8 * XCD_RUN);
+    for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
+        uint32_t idx = b;
+        if (XCD_RUN > 1) {
+            const uint32_t xcd = b & 7u, r = b >> 3;
+            idx = ((r / XCD_RUN) * 8u + xcd) * XCD_RUN + (r % XCD_RUN);
+        }
+        if (idx >= n) continue;
         __syncthreads();
         const uint32_t e = a.cand_list[idx];
         const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
