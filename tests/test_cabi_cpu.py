@@ -90,3 +90,14 @@ def test_headers_are_valid_c99_and_cxx11():
     for cmd in runs:
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0 and "warning" not in r.stderr, (cmd, r.stderr[-2000:])
+
+
+def test_plain_c_caller_links_and_runs_host_only_calls(tmp_path):
+    """tests/cpp/c_caller.c is C99 and links against the library like any C / cgo / FFI caller would; without arguments it only
+    uses host-side entry points (the GPU form runs in tests/test_gpu_shim.py)."""
+    lib = build_library()
+    exe = str(tmp_path / "c_caller")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "c_caller.c"),
+                    "-o", exe, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert out.startswith("version 100 thres 1/7/7 corner 3 warp 56 limits 1920x1080x4 marker_bytes 96 mv15 1")

@@ -136,3 +136,18 @@ def test_shim_member_extrinsics_and_user_decoder(tmp_path):
     m = re.search(r"decoder calls=(\d+) candidates=(\d+)", r.stdout)
     assert m and int(m.group(1)) == len(exp) + int(m.group(2))   # one call per candidate of detectRectangles
     assert "after reset: calls 0 markers %d" % len(exp) in r.stdout
+
+
+def test_plain_c_caller_detects_the_single_still(tmp_path):
+    """tests/cpp/c_caller.c (C99, no C++ runtime of its own) through arucohip_create / arucohip_detect on the reference's single still:
+    the ids of testdata/single/expected.yml."""
+    from aruco_amd import build_library
+
+    lib = build_library()
+    exe_c = str(tmp_path / "c_caller")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "c_caller.c"),
+                    "-o", exe_c, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe_c, os.path.join(GOLDEN, "single.pgm")], stdout=subprocess.PIPE, text=True, check=True).stdout
+    doc = json.load(open(os.path.join(GOLDEN, "single.json")))
+    ids = [int(v) for v in out.strip().splitlines()[-1].split(":")[1].split()]
+    assert ids == [m["id"] for m in doc["markers"]]
