@@ -12,8 +12,9 @@
 
 namespace ah {
 
-__host__ __device__ inline int tiles_x(int width) { return (width + 7) / 8 + 1; }
-__host__ __device__ inline int tiles_y(int height) { return (height + 7) / 8 + 1; }
+// at least 4 x 4 tiles: the followers load 4 x 4-tile blocks, and a frame narrower or lower than 25 pixels still needs one (the extra tiles stay zero)
+__host__ __device__ inline int tiles_x(int width) { const int t = (width + 7) / 8 + 1; return t < 4 ? 4 : t; }
+__host__ __device__ inline int tiles_y(int height) { const int t = (height + 7) / 8 + 1; return t < 4 ? 4 : t; }
 // 128-tile strips of a tile row (one wave of the wide threshold kernel covers one: 64 lanes x 2 tiles)
 __host__ __device__ inline int tile_strips(int width) { return (width + 1023) / 1024; }
 

@@ -858,7 +858,7 @@ static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, 
 static int check_geometry(arucohip_handle* h, int nframes, int W, int H, size_t row_stride, int channels = 1) {
     if (nframes < 1 || nframes > h->lim.max_batch) return fail(h, ARUCOHIP_E_INVALID, "nframes outside 1..max_batch");
     // every device array and packed field is sized per dimension (tile rows, 14-bit checkpoint coordinates, raster keys)
-    if (W < 32 || H < 32 || W > h->lim.max_width || H > h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame wider or taller than the handle was created for");
+    if (W < 1 || H < 1 || W > h->lim.max_width || H > h->lim.max_height) return fail(h, ARUCOHIP_E_INVALID, "frame wider or taller than the handle was created for");
     if (row_stride < (size_t)W * channels) return fail(h, ARUCOHIP_E_INVALID, "row_stride < width * channels");
     return ARUCOHIP_OK;
 }

@@ -287,7 +287,7 @@ struct SharedHandle_ {
         if (!h || width > w || height > hh) {
             arucohip_destroy(h);
             h = nullptr;
-            w = std::max(w, width), hh = std::max(hh, height);
+            w = std::max(std::max(w, width), 32), hh = std::max(std::max(hh, height), 32);
             const char* e = std::getenv("ARUCOHIP_DEVICE");
             arucohip_throw_(arucohip_create(nullptr, e ? std::atoi(e) : 0, w, hh, 1, &h), "arucohip_create", nullptr);
         }
@@ -732,7 +732,7 @@ private:
     }
     void ensure_(int w, int hh) {
         if (h_ && w <= cap_w_ && hh <= cap_h_) return;   // device arrays are sized per dimension
-        w = std::max(w, cap_w_), hh = std::max(hh, cap_h_);
+        w = std::max(std::max(w, cap_w_), 32), hh = std::max(std::max(hh, cap_h_), 32);   // a handle is at least 32 x 32; frames may be smaller
         arucohip_destroy(h_);
         h_ = nullptr;
         arucohip_limits_t lim;

@@ -104,10 +104,10 @@ void arucohip_default_params(arucohip_params_t* p);
 void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height, int max_batch);
 
 /* Create a detector on HIP device `device` able to take frames up to max_width x max_height, `max_batch` at a time.
- * params may be NULL (reference defaults). Frame geometry: 32 <= width, height <= 16383 (14-bit coordinates in the border
- * checkpoints) and width * height <= 2^26 (raster keys); the limits hold per dimension, a frame may be smaller than the handle but
- * not wider or taller. Anything outside is ARUCOHIP_E_INVALID (the reference has no such limits; a frame below 32 pixels in a
- * dimension cannot hold a decodable marker with its quiet zone at the default sizes). */
+ * params may be NULL (reference defaults). Geometry: a handle is at least 32 x 32 and at most 16383 x 16383 (14-bit coordinates in the
+ * border checkpoints) with max_width * max_height <= 2^26 (raster keys); a frame is 1 x 1 up to the handle's size, the limits hold per
+ * dimension (a frame may be smaller than the handle, not wider or taller). Anything outside is ARUCOHIP_E_INVALID; the reference has no
+ * upper limits. */
 int arucohip_create(const arucohip_params_t* params, int device, int max_width, int max_height, int max_batch,
                     arucohip_handle** out);
 int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* limits, arucohip_handle** out);

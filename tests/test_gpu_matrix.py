@@ -200,8 +200,8 @@ def test_extreme_aspect_frames(env, shape):
 
 
 def test_degenerate_frames(env):
-    """Constant, checkered and the smallest frames the library takes (32 pixels in a dimension, include/arucohip.h), a frame below that and
-    an empty batch: nothing is found, nothing faults, the thresholded image still equals the restatement."""
+    """Constant and checkered frames, frames down to one pixel, and an empty batch: nothing faults, thresholded image, borders and markers
+    equal the restatement."""
     import torch
     capi, orc = env["capi"], env["orc"]
     rng = np.random.RandomState(2)
@@ -245,9 +245,34 @@ def test_degenerate_frames(env):
             h.detect_batch_device(fr.data_ptr(), 0, 640, 480, out.data_ptr(), 64, cnt.data_ptr())
         except capi.ArucoHipError as e:
             assert e.code == capi.E_INVALID
-        with pytest.raises(capi.ArucoHipError) as e:                         # below 32 pixels in a dimension: refused, not a fault
-            h.detect(np.zeros((17, 9), np.uint8))
-        assert e.value.code == capi.E_INVALID
         assert len(h.detect(np.full((480, 640), 128, np.uint8))) == 0        # the handle is still usable
+    finally:
+        h.close()
+    # frames far smaller than the smallest handle (32 x 32), down to one pixel, in both border pipelines (a one-frame handle uses the
+    # waypoint segments, a larger one the walkers): thresholded image, kept borders and markers against the oracle
+    def blob(hgt, wid):
+        a = rng.randn(hgt // 3 + 2, wid // 3 + 2)
+        a = np.kron(a, np.ones((3, 3)))[:hgt, :wid]
+        return np.clip(np.where(a > 0, 200, 60) + rng.randint(-3, 4, size=a.shape), 0, 255).astype(np.uint8)
+    for mb in (1, 2):
+        for (hgt, wid) in ((17, 9), (8, 8), (1, 64), (64, 1), (16, 33), (31, 31), (5, 300), (300, 5), (24, 24), (25, 40), (2, 2), (1, 1)):
+            g = blob(hgt, wid)
+            h = capi.Handle(max(wid, 32), max(hgt, 32), max_batch=mb)
+            try:
+                got = h.detect(g)
+                thr = orc.adaptive_threshold(g, 7, 7.0)
+                assert np.array_equal(h.thresholded(0, g.shape), thr), (mb, hgt, wid)
+                lo = int(np.float32(0.04) * np.float32(max(wid, hgt)) * np.float32(4))
+                hi = int(np.float32(0.5) * np.float32(max(wid, hgt)) * np.float32(4))
+                if lo >= 1:        # the walkers never keep 1-point borders (no quad can come from one)
+                    ref = [c for c in orc.find_contours(thr) if lo < len(c["pts"]) < hi]
+                    gc = h.debug_contours(0)
+                    assert len(gc) == len(ref) and all(x["hole"] == y["hole"] and np.array_equal(x["pts"], y["pts"]) for x, y in zip(gc, ref)), (mb, hgt, wid)
+                assert [int(m["id"]) for m in got] == [m["id"] for m in orc.Oracle().detect(g)]
+            finally:
+                h.close()
+    h = capi.Handle(640, 480, max_batch=4)
+    try:
+        assert len(h.detect(np.zeros((17, 9), np.uint8))) == 0
     finally:
         h.close()
