@@ -173,7 +173,10 @@ struct Buffers {
 // share SIMDs with the next batch's streaming threshold waves, which are always ready to issue; at equal priority the
 // dependent chain only gets every n-th issue slot. Raised priority lets the sparse chains issue whenever they can — they leave
 // most slots to the streaming waves anyway.
-__device__ __forceinline__ void latency_bound_priority() { __builtin_amdgcn_s_setprio(3); }
+#ifndef LBP_PRIO
+#define LBP_PRIO 3
+#endif
+__device__ __forceinline__ void latency_bound_priority() { if (LBP_PRIO > 0) __builtin_amdgcn_s_setprio(LBP_PRIO); }
 
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_bgr2gray(hipStream_t s, const uint8_t* bgr, size_t row_stride, size_t frame_stride, int width, int height, int nframes, uint8_t* gray);
