@@ -36,6 +36,7 @@ Tuning read_tuning() {
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
+    t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
     t.thres_lazy = geti("ARUCOHIP_THRES_BYTES", 0) == 0;
     if (const char* e = getenv("ARUCOHIP_GENS")) {
         for (const char* q = e; *q && t.ngens < 32;) {
@@ -315,7 +316,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     b.cap_markers = lim->markers_per_frame;
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(e)
     ALLOC(b.thres, P * px);
-    ALLOC(b.thres_edge, P * (size_t)(2 * lim->max_width + 2 * lim->max_height));
+    ALLOC(b.thres_edge, P * thres_edge_stride(lim->max_width, lim->max_height));
     {   // timing stamps of the wide threshold kernel: its finest grid is one wave per 1024-px strip and 16 rows
         const size_t waves = (size_t)tile_strips(lim->max_width) * ((lim->max_height + 15) / 16) * F;
         ALLOC(b.thr_stamps, 2 * waves * sizeof(uint64_t));
@@ -1569,7 +1570,11 @@ int arucohip_set_pipeline_depth(arucohip_handle* h, int depth) {
     for (int i = 0; i < depth; i++) {
         arucohip_handle* l = nullptr;
         int rc = arucohip_create_ex(&h->params, h->device, &h->lim, &l);
-        if (rc != ARUCOHIP_OK) return fail(h, rc, "creating a pipeline lane failed");
+        if (rc != ARUCOHIP_OK) {   // all or nothing: a later submit must not run at a smaller depth than the caller asked for
+            for (auto* made : h->lanes) arucohip_destroy(made);
+            h->lanes.clear();
+            return fail(h, rc, "creating a pipeline lane failed (no lanes kept)");
+        }
         l->decoder_fn = h->decoder_fn, l->decoder_user = h->decoder_user;
         for (auto* k : l->kids) k->decoder_fn = h->decoder_fn, k->decoder_user = h->decoder_user;
         l->timing = h->timing;
@@ -1577,7 +1582,11 @@ int arucohip_set_pipeline_depth(arucohip_handle* h, int depth) {
         if (h->d_hrm && h->hrm_count > 0) {
             std::vector<uint64_t> codes(h->hrm_count);
             HIPCHK(h, hipMemcpy(codes.data(), h->d_hrm, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            if ((rc = arucohip_set_dictionary(l, h->hrm_n, h->hrm_count, codes.data(), h->hrm_tau0, h->hrm_rate))) return rc;
+            if ((rc = arucohip_set_dictionary(l, h->hrm_n, h->hrm_count, codes.data(), h->hrm_tau0, h->hrm_rate))) {
+                for (auto* made : h->lanes) arucohip_destroy(made);
+                h->lanes.clear();
+                return rc;
+            }
         }
     }
     return ARUCOHIP_OK;

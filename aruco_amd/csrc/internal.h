@@ -121,8 +121,16 @@ struct Tuning {
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
+    int threshold_eo = 1;      // ARUCOHIP_THRESHOLD_EO: its round-3 form for 7x7 blocks (unpacked row ring, folded constants); 0 = the round-2 kernel
 };
 Tuning read_tuning();          // capi.hip
+
+// Border lines of a thresholded plane kept beside the bit tiles (lazy byte image): row 0 at 0, row H-1 at Wp, column 0 at 2 Wp, column W-1
+// at 2 Wp + Hp, with Wp / Hp = width / height rounded up to 16 so that every line starts 16-byte aligned (the kernels store 16 and 4 bytes
+// at a time) and the virtual rows that complete the last tile row have somewhere to go.
+__host__ __device__ inline size_t thres_edge_wp(int W) { return (size_t)((W + 15) & ~15); }
+__host__ __device__ inline size_t thres_edge_hp(int H) { return (size_t)((H + 15) & ~15); }
+__host__ __device__ inline size_t thres_edge_stride(int W, int H) { return 2 * thres_edge_wp(W) + 2 * thres_edge_hp(H); }
 
 // device pointers + capacities handed to kernels
 struct Buffers {
@@ -140,7 +148,7 @@ struct Buffers {
     uint32_t* gen_cnt;     // counters of the long-walk generation lists (k_contours.hip), zeroed per batch
     ContourDesc* cdesc;
     short2* pool;
-    uint8_t* thres_edge;    // [P][2 W + 2 H] border lines of the thresholded planes when the byte image is left out (k_threshold.hip)
+    uint8_t* thres_edge;    // [P][thres_edge_stride(W, H)] border lines of the thresholded planes when the byte image is left out (k_threshold.hip)
     uint64_t* thr_stamps;   // timing: per-wave device-clock stamps of the wide threshold kernel [2 * waves]
     uint64_t* thr_acc;      // timing: {clock ticks, launches} accumulated by stamp_reduce_kernel
     int thr_stamp_on;       // stamps are taken (arucohip_enable_timing)

@@ -38,6 +38,7 @@ struct ThrArgs {
     int fast;             // width, strides and base address are multiples of 4: dword loads and stores (template FAST)
     int fast16;           // ... multiples of 16 and width >= 16: the 16-pixel-per-lane kernel applies
     int wide_ok;          // Tuning::threshold_wide
+    int eo_ok;            // Tuning::threshold_eo
     uint8_t* thres;
     uint64_t* tiles;
     uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
@@ -394,11 +395,12 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
             } else {
                 // The byte image is not written: the tiles below hold it as bits except for its four border lines (cleared there,
                 // as cv::findContours does), which go to a side array; expand_thres_kernel rebuilds the bytes when they are asked for.
-                uint8_t* e = a.edge + (size_t)plane * (2 * W + 2 * H);
+                const size_t Wp = thres_edge_wp(W), Hp = thres_edge_hp(H);
+                uint8_t* e = a.edge + (size_t)plane * thres_edge_stride(W, H);
                 if (c == 0) *(u32x4*)(e + xa) = tv;
-                if (c == H - 1) *(u32x4*)(e + W + xa) = tv;
-                if (x == 0) e[2 * W + c] = (uint8_t)(t4[0] & 0xFFu);
-                if (x == W - 16) e[2 * W + H + c] = (uint8_t)(t4[3] >> 24);
+                if (c == H - 1) *(u32x4*)(e + Wp + xa) = tv;
+                if (x == 0) e[2 * Wp + c] = (uint8_t)(t4[0] & 0xFFu);
+                if (x == W - 16) e[2 * Wp + Hp + c] = (uint8_t)(t4[3] >> 24);
             }
         }
         // ---- binary image for contour purposes, frame cleared: one byte per tile row and tile column
@@ -452,6 +454,252 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the 16-pixel-per-lane pass for 7x7 blocks rebuilt around what the instructions cost on this part (tools/mb_isa.hip,
+// profiles/r03_isa_rates.txt: a 32-bit-encoded VOP2 issues in 1.1 ns per SIMD with four waves per SIMD, everything in a 64-bit encoding —
+// v_perm, v_alignbyte, v_pk_*, v_add3, DPP — in 1.85 ns, v_mqsad_pk_u16_u8 in 6.9 ns). Same memory pattern as above (one 16-byte
+// load per lane and row, PF rows in flight); what changed is the arithmetic per 16 pixels, 140 -> 78 vector instructions:
+//   * every gray row is unpacked ONCE into u16 pairs E = (g0, g2), O = (g1, g3) per dword and stays in a register ring for the seven
+//     rows it is in the window: the column sums take the leaving row from there (no second unpack) and the compare takes the centre row
+//     from there (no third);
+//   * all constants of the test ride along: the unpack writes g + 256 (byte 1 of each pair is the constant 1 from the v_perm's other
+//     source), the column sums start from 7 * 256 plus an offset per column that repeats with period 7 and sums to n/2 - C n over any
+//     seven neighbouring columns, so the horizontal sums come out as S' = S + 49 * 256 + n/2 - C n without a single extra addition, all
+//     sums stay non-negative 16-bit fields of plain 32-bit adds, and  e = S' - (g + 256) n  is one v_pk_mad_u16 with the multiplier -n:
+//     its sign bit says "black";
+//   * the horizontal 7-sums are built from pair sums T = E + O: U_d = (T_d.hi, T_d+1.lo) is one v_alignbyte per dword (round 2 shifted E
+//     and O separately), C_d = T_d + U_d + U_d-1 one v_add3, S(E_d) = C_d + O_d-1 and S(O_d) = C_d + E_d+1 one add each;
+//   * a tile-row byte is two v_dot4_i32_i8 of the 0 / -1 "black" bytes with the weights 1, 2, 4 ... 64, -128 (zero for the image's first
+//     and last column) on top of the mask of the allowed pixels: modulo 256 that is the byte of the WHITE pixels; the first and the last
+//     image row are cleared when the tile is stored, not per row;
+//   * the border columns of the lazy byte image are collected four rows at a time (round 2 stored a byte per row from a divergent branch).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SEL_E256 = 0x04020400u, SEL_O256 = 0x04030401u;   // v_perm(0x01010101, x, .): (x.b0 | 256, x.b2 | 256) and (x.b1 | 256, x.b3 | 256)
+
+template <int PF, int SEGW, bool LAZY>
+__device__ __forceinline__ void threshold_eo_body(const ThrArgs& a) {
+    constexpr int R = 3, RING = 7;
+    static_assert(PF >= 1 && PF <= 7, "rows of prefetch");
+    constexpr int UNROLL = (RING % PF == 0) ? RING : RING * PF;   // ring slots and prefetch slots are compile-time constants inside a turn
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.z;
+    const int W = a.width, H = a.height;
+    const int x = (int)blockIdx.x * WSTRIP + 16 * lane;                        // first pixel of this lane
+    const int ys = (int)blockIdx.y * SEGW, ye = min(ys + SEGW, H);
+    const int ye8 = (ye + 7) & ~7;
+    const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
+    const int plane = frame * a.nthr + a.t;
+    uint8_t* tdst = LAZY ? nullptr : a.thres + (size_t)plane * W * H;
+    uint64_t* bdst = a.tiles + (size_t)plane * a.tnx * a.tny;
+    const size_t Wp = thres_edge_wp(W), Hp = thres_edge_hp(H);
+    uint8_t* edge = LAZY ? a.edge + (size_t)plane * thres_edge_stride(W, H) : nullptr;
+
+    const bool out_lane = x < W;
+    const bool last_lane = x == W - 16;                                        // holds the image's last column
+    const uint32_t xa = (uint32_t)min(x, W - 16);                              // W is a multiple of 16
+    // a lane right of the image loads the row's last 16 pixels; its first dword becomes that row's last pixel four times
+    // (BORDER_REPLICATE in x) — the only dword of it its left neighbour, the last lane of the image, ever looks at
+    const uint32_t rep_sel = x >= W ? 0x07070707u : 0x03020100u;
+    // halo: lane 0 needs the dword left of the strip, lane 63 the dword right of it. EVERY lane loads a dword (the others their own first
+    // one: the same line as their row load), so the load sits in the straight-line code next to the row load and is waited for PF rows
+    // later like it; a load under `if (edge lane)` has its own wait right behind it, which drains the whole prefetch queue every row.
+    // BORDER_REPLICATE in x is part of the unpack selectors.
+    const int xp = lane == 0 ? x - 4 : x + 16;
+    const bool edge_lane = lane == 0 || lane == 63;
+    const uint32_t hxa = edge_lane ? (uint32_t)min(max(xp, 0), W - 4) : xa;
+    const uint32_t hselE = xp < 0 ? 0x04000400u : (xp >= W ? 0x04030403u : SEL_E256), hselO = xp < 0 ? 0x04000400u : (xp >= W ? 0x04030403u : SEL_O256);
+    auto from_left_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false); };
+    auto from_right_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false); };
+
+    // ---- constants of the test folded into the sums (see the header): column offsets with period 7
+    const int off = a.n_half - a.idelta * a.n;                                 // white <=> S + off - g n >= 0
+    const int q = (off >= 0 ? off : off - (RING - 1)) / RING, rem = off - RING * q;   // floor division; 0 <= rem < 7
+    auto col_init = [&](int col) -> uint32_t {                                 // start value of column col's sum: seven virtual rows of g = 0
+        const int m = ((col % RING) + RING) % RING;
+        return (uint32_t)(RING * 256 + q + (m < rem ? 1 : 0));                 // >= 0: the host only takes this kernel for |C| <= 200
+    };
+    uint32_t VE[4], VO[4], VEh, VOh;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        VE[d] = col_init(x + 4 * d) | (col_init(x + 4 * d + 2) << 16);
+        VO[d] = col_init(x + 4 * d + 1) | (col_init(x + 4 * d + 3) << 16);
+    }
+    VEh = col_init(xp) | (col_init(xp + 2) << 16), VOh = col_init(xp + 1) | (col_init(xp + 3) << 16);
+    // window rows as u16 pairs (+ 256), the strip's halo dword raw; the virtual rows they start with are g = 0
+    uint32_t RE[RING][4], RO[RING][4], RH[RING];
+#pragma unroll
+    for (int k = 0; k < RING; k++) {
+        RH[k] = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) RE[k][d] = 0x01000100u, RO[k][d] = 0x01000100u;
+    }
+    uint4 G[PF];
+    uint32_t GH[PF];
+    const uint32_t K1 = 0x01010101u;
+    const uint32_t negn = (uint32_t)((65536 - a.n) & 0xFFFF) * 0x00010001u;
+    // tile-row weights: dwords 0 / 2 carry bits 0..3 of their tile's row byte, dwords 1 / 3 bits 4..7; the image's first and last column
+    // stay clear (cv::findContours' frame); wsum = the byte of all allowed pixels
+    uint32_t wq[4], wsum[2] = {0, 0};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        wq[d] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int bit = 4 * (d & 1) + j, px = x + 4 * d + j;
+            if (px >= 1 && px <= W - 2) wq[d] |= (bit == 7 ? 0x80u : (1u << bit)) << (8 * j), wsum[d >> 1] |= 1u << bit;
+        }
+    }
+    uint32_t tA0 = 0, tA1 = 0, tB0 = 0, tB1 = 0;        // the last 8 tile-row bytes of the lane's two tile columns (64-bit shift registers)
+    uint32_t colL = 0, colR = 0;                        // black bytes of the image's first / last column, the last 4 rows
+    const int r_begin = ys - R;
+    // address of the row that is loaded next: rows above / below the image repeat its first / last row (BORDER_REPLICATE in y)
+    int r_next = r_begin;
+    const uint8_t* p_next = src + (size_t)min(max(r_next, 0), H - 1) * a.row_stride;
+    auto issue_loads = [&](const int kp) {
+        G[kp] = *(const uint4*)(p_next + xa);
+        GH[kp] = *(const uint32_t*)(p_next + hxa);
+        if (r_next >= 0 && r_next < H - 1) p_next += a.row_stride;
+        r_next++;
+    };
+
+    // Step s: gray row r_begin + s enters the window (ring slot k = s % 7; it was loaded PF steps ago into prefetch slot kp = s % PF, which
+    // takes row s + PF right after); STEADY = the window is complete, its centre row s - R is thresholded.
+    auto step = [&](const int k, const int kp, const int s, const bool steady) {
+        const int c = r_begin + s - R;
+        {
+            const uint4 Dn = G[kp];
+            const uint32_t nw[4] = {__builtin_amdgcn_perm(Dn.w, Dn.x, rep_sel), Dn.y, Dn.z, Dn.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t en = __builtin_amdgcn_perm(K1, nw[d], SEL_E256), on = __builtin_amdgcn_perm(K1, nw[d], SEL_O256);
+                VE[d] = VE[d] + en - RE[k][d], VO[d] = VO[d] + on - RO[k][d];
+                RE[k][d] = en, RO[k][d] = on;
+            }
+            const uint32_t hn = GH[kp], ho = RH[k];
+            VEh = VEh + __builtin_amdgcn_perm(K1, hn, hselE) - __builtin_amdgcn_perm(K1, ho, hselE);
+            VOh = VOh + __builtin_amdgcn_perm(K1, hn, hselO) - __builtin_amdgcn_perm(K1, ho, hselO);
+            RH[k] = hn;
+        }
+        issue_loads(kp);
+        if (!steady) return;
+        // ---- horizontal sums of the column sums
+        uint32_t T[6];                                   // T[d + 1] = pair sums of dword d, d = -1 (left lane) .. 4 (right lane)
+#pragma unroll
+        for (int d = 0; d < 4; d++) T[d + 1] = VE[d] + VO[d];
+        const uint32_t Th = VEh + VOh;
+        T[0] = from_left_h(T[4], Th), T[5] = from_right_h(T[1], Th);
+        const uint32_t Om1 = from_left_h(VO[3], VOh), E4 = from_right_h(VE[0], VEh);
+        uint32_t U[5];                                   // U[d + 1] = (T_d.hi, T_d+1.lo)
+#pragma unroll
+        for (int d = 0; d < 5; d++) U[d] = __builtin_amdgcn_alignbyte(T[d + 1], T[d], 2);
+        const int kc = (k + RING - R) % RING;            // slot of the centre row
+        uint32_t tb[4];                                  // "black" bytes of the centre row: 255 = black
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t C = T[d + 1] + U[d + 1] + U[d];
+            const uint32_t sE = C + (d == 0 ? Om1 : VO[d - 1]), sO = C + (d == 3 ? E4 : VE[d + 1]);
+            typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+            const ushort2v n2 = __builtin_bit_cast(ushort2v, negn);
+            const ushort2v eE = __builtin_bit_cast(ushort2v, RE[kc][d]) * n2 + __builtin_bit_cast(ushort2v, sE);
+            const ushort2v eO = __builtin_bit_cast(ushort2v, RO[kc][d]) * n2 + __builtin_bit_cast(ushort2v, sO);
+            tb[d] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, eO), __builtin_bit_cast(uint32_t, eE), 0x0B090A08u);
+        }
+        // ---- the thresholded bytes, where somebody wants them
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (!LAZY) {
+            if (c < ye && out_lane) {
+                const u32x4 tv = {~tb[0], ~tb[1], ~tb[2], ~tb[3]};
+                __builtin_nontemporal_store(tv, (u32x4*)(tdst + (size_t)c * W + xa));
+            }
+        } else {
+            // the byte image is not written: the tiles below hold it as bits except for its four border lines (cleared there, as
+            // cv::findContours does), which go to a side array; expand_thres_kernel rebuilds the bytes when they are asked for
+            if (c == 0 || c == H - 1) {
+                if (out_lane) {
+                    const u32x4 tv = {~tb[0], ~tb[1], ~tb[2], ~tb[3]};
+                    *(u32x4*)(edge + (c == 0 ? 0 : Wp) + xa) = tv;
+                }
+            }
+            colL = __builtin_amdgcn_perm(tb[0], colL, 0x04030201u);   // drop the oldest row, append byte 0 of dword 0 ...
+            colR = __builtin_amdgcn_perm(tb[3], colR, 0x07030201u);   // ... and byte 3 of dword 3
+            if ((c & 3) == 3) {
+                if (x == 0) *(uint32_t*)(edge + 2 * Wp + (c - 3)) = ~colL;
+                if (last_lane) *(uint32_t*)(edge + 2 * Wp + Hp + (c - 3)) = ~colR;
+            }
+        }
+        // ---- binary image for contour purposes: one byte per tile row and tile column. black bytes are -1: the dot products take the
+        // black pixels' weights off the allowed mask (the -128 of bit 7 is +128 modulo 256, and only the low byte is kept)
+        const uint32_t rbA = (uint32_t)__builtin_amdgcn_sdot4((int)tb[1], (int)wq[1], __builtin_amdgcn_sdot4((int)tb[0], (int)wq[0], (int)wsum[0], false), false);
+        const uint32_t rbB = (uint32_t)__builtin_amdgcn_sdot4((int)tb[3], (int)wq[3], __builtin_amdgcn_sdot4((int)tb[2], (int)wq[2], (int)wsum[1], false), false);
+        tA0 = __builtin_amdgcn_alignbyte(tA1, tA0, 1), tA1 = __builtin_amdgcn_alignbyte(rbA, tA1, 1);   // rows enter at the top byte
+        tB0 = __builtin_amdgcn_alignbyte(tB1, tB0, 1), tB1 = __builtin_amdgcn_alignbyte(rbB, tB1, 1);
+        if ((c & 7) == 7) {
+            // rows that are not part of the contour image: the image's first row, its last row and the virtual rows below it
+            const int ty = c >> 3;
+            uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
+            if (ty == 0) mlo = 0xFFFFFF00u;
+            if (ty == ((H - 1) >> 3)) {
+                const int b = (H - 1) & 7;           // rows b .. 7 of this tile row go
+                const uint64_t keep = (1ull << (8 * b)) - 1ull;
+                mlo &= (uint32_t)keep, mhi &= (uint32_t)(keep >> 32);
+            }
+            const uint32_t a0 = tA0 & mlo, a1 = tA1 & mhi, b0 = tB0 & mlo, b1 = tB1 & mhi;
+            if (out_lane) {
+                uint64_t* t = bdst + (size_t)ty * a.tnx + (x >> 3);   // 8-byte aligned (the tile row length is odd): two stores, not one 16-byte vector
+                t[0] = (uint64_t)a0 | ((uint64_t)a1 << 32);
+                t[1] = (uint64_t)b0 | ((uint64_t)b1 << 32);
+            }
+            // which of the strip's 128 tiles hold a pixel: the start-candidate kernel only visits those (and their right / lower neighbours)
+            const unsigned long long balA = __ballot(out_lane && (a0 | a1) != 0u), balB = __ballot(out_lane && (b0 | b1) != 0u);
+            if (lane == 0) {
+                uint64_t* bw = a.tile_bits + ((size_t)plane * a.tny + ty) * (2 * a.nstrips) + 2 * blockIdx.x;
+                bw[0] = balA, bw[1] = balB;
+            }
+        }
+    };
+
+    const int s_last = ye8 - 1 + R - r_begin;   // >= 7 + 2R
+    // prologue: PF rows in flight before the first one is used
+#pragma unroll
+    for (int k = 0; k < PF; k++) issue_loads(k);
+#pragma unroll
+    for (int s = 0; s < 2 * R; s++) step(s % RING, s % PF, s, false);   // the first 2R rows only replace virtual rows
+    // up to the first whole turn
+#pragma unroll
+    for (int s = 2 * R; s < UNROLL; s++) {
+        if (s > s_last) return;
+        step(s % RING, s % PF, s, true);
+    }
+    int s0 = UNROLL;
+    for (; s0 + UNROLL - 1 <= s_last; s0 += UNROLL) {                   // whole turns: straight-line code, every slot is a constant
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) step(k % RING, k % PF, s0 + k, true);
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL - 1; k++) {
+        if (s0 + k > s_last) return;
+        step(k % RING, k % PF, s0 + k, true);
+    }
+}
+
+#ifndef THR_EO_WAVES
+#define THR_EO_WAVES 3
+#endif
+template <int PF, int SEGW, bool LAZY>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(THR_EO_WAVES, THR_EO_WAVES))) void threshold_eo_kernel(ThrArgs a) {
+    uint64_t t0 = 0;
+    if (a.stamps) t0 = wall_clock64();
+    threshold_eo_body<PF, SEGW, LAZY>(a);
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);   // the wave's stores have left
+        const uint64_t t1 = wall_clock64();
+        if (threadIdx.x == 0) {
+            const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            a.stamps[2 * w] = t0, a.stamps[2 * w + 1] = t1;
+        }
+    }
+}
+
 // With hipEvent timing on, every wave also leaves the device clock (constant rate, hipDeviceAttributeWallClockRate) at its start and
 // after its last store; stamp_reduce_kernel turns them into the launch's execution span. With several batches in flight the hipEvent
 // interval around the launch also contains the time the dispatch waits for wave slots other batches' kernels hold; the span from the
@@ -491,13 +739,14 @@ __global__ __launch_bounds__(256) void expand_thres_kernel(const uint64_t* __res
     const int x8 = 8 * (int)(blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
     if (x8 >= W) return;
     const uint32_t bits = (uint32_t)(tiles[(size_t)(y >> 3) * tnx + (x8 >> 3)] >> (8 * (y & 7))) & 0xFFu;
+    const size_t Wp = thres_edge_wp(W), Hp = thres_edge_hp(H);
     for (int j = 0; j < 8 && x8 + j < W; j++) {
         const int x = x8 + j;
         uint8_t v = (uint8_t)(((bits >> j) & 1u) * 255u);
         if (y == 0) v = edge[x];
-        else if (y == H - 1) v = edge[W + x];
-        else if (x == 0) v = edge[2 * W + y];
-        else if (x == W - 1) v = edge[2 * W + H + y];
+        else if (y == H - 1) v = edge[Wp + x];
+        else if (x == 0) v = edge[2 * Wp + y];
+        else if (x == W - 1) v = edge[2 * Wp + Hp + y];
         dst[(size_t)y * W + x] = v;
     }
 }
@@ -505,7 +754,7 @@ __global__ __launch_bounds__(256) void expand_thres_kernel(const uint64_t* __res
 void launch_expand_thres(hipStream_t s, const FrameGeom& g, int plane, const Buffers& b) {
     const int W = g.width, H = g.height, tnx = tiles_x(W), tny = tiles_y(H);
     hipLaunchKernelGGL(expand_thres_kernel, dim3((W / 8 + 256) / 256, H), dim3(256), 0, s, b.tiles + (size_t)plane * tnx * tny,
-                       b.thres_edge + (size_t)plane * (2 * W + 2 * H), W, H, tnx, b.thres + (size_t)plane * W * H);
+                       b.thres_edge + (size_t)plane * thres_edge_stride(W, H), W, H, tnx, b.thres + (size_t)plane * W * H);
 }
 
 // the non-empty-tile bitmap for the paths whose kernel does not write it (narrow / FIXED / caller-supplied binary image): one
@@ -543,6 +792,28 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes, unsigned l
             const int strips = (a.width + WSTRIP - 1) / WSTRIP;
             const long waves128 = (long)strips * ((a.height + 127) / 128) * nframes;
             int segs;
+            if constexpr (R == 3) {
+                if (a.eo_ok && abs(a.idelta) <= 200) {   // the round-3 form of this pass (7x7 blocks; its folded constants want a moderate C)
+                    const dim3 blk(64);
+#define EO_LAUNCH(SEG_)                                                                                                               \
+    do {                                                                                                                              \
+        segs = (a.height + (SEG_) - 1) / (SEG_);                                                                                      \
+        if (a.thres)                                                                                                                  \
+            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, false>), dim3(strips, segs, nframes), blk, 0, s, a);                \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, true>), dim3(strips, segs, nframes), blk, 0, s, a);                 \
+    } while (0)
+                    if (waves128 >= 512)
+                        EO_LAUNCH(128);
+                    else if (waves128 * 4 >= 512)
+                        EO_LAUNCH(32);
+                    else
+                        EO_LAUNCH(16);
+#undef EO_LAUNCH
+                    if (a.stamps) hipLaunchKernelGGL(stamp_reduce_kernel, dim3(1), dim3(1024), 0, s, a.stamps, (size_t)strips * segs * nframes, stamp_acc);
+                    return true;
+                }
+            }
             if (waves128 >= 512) {
                 segs = (a.height + 127) / 128;
                 hipLaunchKernelGGL((threshold_wide_kernel<R, THR_PF, 128>), dim3(strips, segs, nframes), dim3(64), 0, s, a);
@@ -570,7 +841,7 @@ static void fill_args(ThrArgs& a, const uint8_t* gray, const FrameGeom& g, const
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride;
     a.width = g.width, a.height = g.height, a.nthr = nthr, a.t = t;
     a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
-    a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width), a.wide_ok = b.tune.threshold_wide;
+    a.thres = b.thres, a.tiles = b.tiles, a.tile_bits = b.tile_bits, a.nstrips = tile_strips(g.width), a.wide_ok = b.tune.threshold_wide, a.eo_ok = b.tune.threshold_eo;
     a.idelta = 0, a.n = 1, a.n_half = 0;
     a.stamps = b.thr_stamp_on ? b.thr_stamps : nullptr;
     a.edge = nullptr;

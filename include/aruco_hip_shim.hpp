@@ -602,12 +602,13 @@ public:
     // markerdetector.h:243-245. The library's two decoders select the device kernels; any other function is called on the
     // host with the canonical patch the device warped (contract: markerdetector.h:65-77), the pipeline continues on the device.
     void setMakerDetectorFunction(MarkerdetectorFunc markerdetector_func) {
+        // a null function changes nothing: the detector keeps the decoder it had (the check comes before any member is touched)
+        if (!markerdetector_func) arucohip_throw_(ARUCOHIP_E_INVALID, "setMakerDetectorFunction: null function", nullptr);
         user_fn_ = nullptr, hrm_ = false;
         if (markerdetector_func == &HighlyReliableMarkers::detect)
             hrm_ = true;
         else if (markerdetector_func != &FiducidalMarkers::detect)
             user_fn_ = markerdetector_func;
-        if (!markerdetector_func) arucohip_throw_(ARUCOHIP_E_INVALID, "setMakerDetectorFunction: null function", nullptr);
         p_.decoder_kind = user_fn_ ? ARUCOHIP_DECODER_USER : hrm_ ? ARUCOHIP_DECODER_HRM : ARUCOHIP_DECODER_FIDUCIAL_5X5;   // part of the parameter set from now on
         hrm_version_ = -1;
         if (h_) apply_decoder_();

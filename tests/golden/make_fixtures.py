@@ -14,6 +14,12 @@ Run in the build container only (needs /root/reference/testdata). Outputs are da
   * hrm.pgm / hrm.json  testdata/hrm (highly reliable markers, test/core_tests.cpp:310-353): frame, expected markers,
                         intrinsics (resized to the frame like the test does), the 4x4 dictionary d4x4_100.yml
                         (marker bit strings, tau0) and the detector settings the test applies.
+  * hrm_dictionaries.json  the reference's larger dictionaries testdata/hrm/dictionaries/d5x5_100 .. d8x8_100.yml (marker bit
+                        strings + tau0), which its HRM apps load; d4x4_100 is part of hrm.json.
+  * create_marker.json  the CreateMarker goldens (test/core_tests.cpp:32-75, marker id 471, 500 px): the 7x7 cell matrix
+                        decoded from testdata/board/marker-expected.png (every cell checked to be uniform 0 / 255) and, from
+                        locked-marker-expected.png (750 px), the geometry of the locked-corner variant. Pins the bit layout
+                        aruco_amd/synth.py::marker_bits draws.
 No reference source text is copied; only test inputs and expected outputs.
 """
 import json
@@ -128,6 +134,31 @@ def main():
     # requires that detection goes through (same dictionary and settings, warp size 48)
     rgb = np.asarray(Image.open(os.path.join(REF, "hrm/refine-fail.png")).convert("RGB"))
     write_pgm(os.path.join(OUT, "hrm_refine_fail.pgm"), bgr2gray_cv3(rgb))
+    # the larger dictionaries the reference ships (row f1)
+    dicts = {}
+    for n in (5, 6, 7, 8):
+        d = load_cv_yaml(os.path.join(REF, "hrm/dictionaries/d%dx%d_100.yml" % (n, n)))
+        assert int(d["markersize"]) == n
+        dicts["d%dx%d_100" % (n, n)] = {"n": n, "tau0": int(d["tau0"]),
+                                        "markers": [str(d["marker_%d" % i]).zfill(n * n) for i in range(int(d["nmarkers"]))]}
+    with open(os.path.join(OUT, "hrm_dictionaries.json"), "w") as f:
+        json.dump(dicts, f, indent=1)
+    # CreateMarker goldens (test/core_tests.cpp:32-75): id 471 at 500 px; 500 / 7 is not an integer, createMarkerImage draws
+    # cell (y, x) at [y*swidth, (y+1)*swidth) with swidth = 500 / 7 = 71 (integer division) and leaves the rest black
+    img = np.asarray(Image.open(os.path.join(REF, "board/marker-expected.png")).convert("L"))
+    assert img.shape == (500, 500) and set(np.unique(img)) <= {0, 255}
+    sw = 500 // 7
+    cells = np.zeros((7, 7), int)
+    for y in range(7):
+        for x in range(7):
+            blk = img[y * sw:(y + 1) * sw, x * sw:(x + 1) * sw]
+            assert blk.min() == blk.max(), "cell (%d, %d) of marker-expected.png is not uniform" % (y, x)
+            cells[y, x] = 1 if blk[0, 0] == 255 else 0
+    assert img[7 * sw:, :].max() == 0 and img[:, 7 * sw:].max() == 0
+    locked = np.asarray(Image.open(os.path.join(REF, "board/locked-marker-expected.png")).convert("L"))
+    with open(os.path.join(OUT, "create_marker.json"), "w") as f:
+        json.dump({"source": "testdata/board/marker-expected.png", "marker_id": 471, "pix_size": 500, "cell_px": sw,
+                   "cells": cells.tolist(), "locked_size": list(locked.shape)}, f, indent=1)
     gl = load_cv_yaml(os.path.join(REF, "board/expected_gl.yml"))
     with open(os.path.join(OUT, "board_gl.json"), "w") as f:
         json.dump({"gldata": [[float(v) for v in row] for row in gl["gldata"]]}, f, indent=1)

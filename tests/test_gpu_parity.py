@@ -460,11 +460,12 @@ def test_hrm_decoder(env):
 
 
 def test_hrm_larger_dictionaries(env):
-    """6x6 and 8x8 dictionaries (64-bit codes, all 64 lanes vote): device == CPU restatement on synthetic frames."""
-    from tests.util import make_hrm_dictionary
+    """The reference's own 5x5 ... 8x8 dictionaries (testdata/hrm/dictionaries/d5x5_100 ... d8x8_100.yml, committed as
+    tests/golden/hrm_dictionaries.json; 8x8 = 64-bit codes, all 64 lanes vote): device == CPU restatement on synthetic frames."""
+    from tests.util import load_hrm_dictionary
     capi, orc, synth = env["capi"], env["orc"], env["synth"]
-    for n, tau in ((6, 9), (8, 14)):
-        D = make_hrm_dictionary(n, 30, tau)
+    for n in (5, 6, 7, 8):
+        D, tau = load_hrm_dictionary(n)
         fr, lay = synth.make_hrm_frame(D, width=1280, height=720, seed=7 + n, n_markers=10, device="cuda")
         g = fr.cpu().numpy()
         h = capi.Handle(1280, 720, max_batch=1)

@@ -1,4 +1,6 @@
 """Known-answer and property tests of the oracle's stages (independent numpy maths, no GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -119,14 +121,35 @@ def test_bgr2gray_matches_the_fixture_pipeline():
 
 
 def test_hrm_synthetic_6x6_and_8x8():
-    """Larger dictionaries of row f1 (the reference ships d6x6 ... d8x8): the restatement finds exactly the rendered markers
-    of a synthetic frame (MarkerCode::getImg layout), in any orientation."""
+    """Larger dictionaries of row f1, the reference's own (testdata/hrm/dictionaries/d5x5_100 ... d8x8_100.yml as committed in
+    tests/golden/hrm_dictionaries.json): the restatement finds exactly the rendered markers of a synthetic frame
+    (MarkerCode::getImg layout), in any orientation."""
     from aruco_amd import synth
-    from tests.util import make_hrm_dictionary
-    for n, tau in ((6, 9), (8, 14)):
-        D = make_hrm_dictionary(n, 30, tau)
+    from tests.util import load_hrm_dictionary
+    for n in (5, 6, 7, 8):
+        D, tau = load_hrm_dictionary(n)
         fr, lay = synth.make_hrm_frame(D, width=1280, height=720, seed=7 + n, n_markers=10)
         o = orc.Oracle(warp_size=(n + 2) * 8)
         o.set_hrm_dictionary(D, tau)
         ms = o.detect(fr.numpy())
         assert [m["id"] for m in ms] == sorted(m["id"] for m in lay)
+
+
+def test_marker_bit_layout_equals_the_create_marker_golden():
+    """Aruco.CreateMarker (test/core_tests.cpp:32-75 <-> testdata/board/marker-expected.png, id 471 at 500 px): the 7x7 cell matrix
+    decoded from that PNG (tests/golden/create_marker.json) is what the synthetic generator draws for id 471, and a frame
+    rendered from the golden cells decodes to 471 in the restatement."""
+    import json
+    from tests.util import GOLDEN
+    doc = json.load(open(os.path.join(GOLDEN, "create_marker.json")))
+    cells = np.array(doc["cells"], np.uint8)
+    assert doc["marker_id"] == 471 and cells.shape == (7, 7)
+    assert np.array_equal(synth.marker_bits(471), cells)
+    # the golden image itself, rebuilt from its cells at the test's size (500 px, 71-px cells, the remainder black), on a white sheet
+    sw = doc["cell_px"]
+    img = np.zeros((500, 500), np.uint8)
+    img[:7 * sw, :7 * sw] = np.kron(cells, np.ones((sw, sw), np.uint8)) * 255
+    frame = np.full((1000, 1400), 255, np.uint8)   # contour of ~2000 points < 0.5 * 1400 * 4
+    frame[100:600, 200:700] = img
+    ms = orc.Oracle().detect(frame)
+    assert [m["id"] for m in ms] == [471]

@@ -14,6 +14,16 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-12))
 
 
+def load_hrm_dictionary(n):
+    """(bit strings, tau0) of the reference's d<n>x<n>_100 dictionary (tests/golden/hrm_dictionaries.json; d4x4_100 lives in hrm.json)."""
+    if n == 4:
+        d = json.load(open(os.path.join(GOLDEN, "hrm.json")))["dictionary"]
+    else:
+        d = json.load(open(os.path.join(GOLDEN, "hrm_dictionaries.json")))["d%dx%d_100" % (n, n)]
+    assert d["n"] == n
+    return list(d["markers"]), int(d["tau0"])
+
+
 def make_hrm_dictionary(n, count, tau, seed=3):
     """Random n x n dictionary (bit strings) whose markers differ from each other and from their own rotations in at least
     `tau` cells — a stand-in for the reference's d6x6 / d8x8 dictionaries."""
