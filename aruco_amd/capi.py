@@ -72,6 +72,8 @@ SYMBOLS = [
     "arucohip_set_pipeline_depth", "arucohip_detect_batch_submit", "arucohip_detect_batch_wait",
     "arucohip_mgpu_device_count", "arucohip_mgpu_create", "arucohip_mgpu_destroy", "arucohip_mgpu_size", "arucohip_mgpu_handle",
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
+    "arucohip_mgpu_set_depth", "arucohip_mgpu_submit_batch", "arucohip_mgpu_submit_streams", "arucohip_mgpu_wait",
+    "arucohip_compact_bytes", "arucohip_compact_markers", "arucohip_wait_event",
 ]
 
 _lib = None
@@ -155,10 +157,31 @@ def load():
     L.arucohip_mgpu_last_error_string.restype = C.c_char_p
     L.arucohip_mgpu_detect_batch.argtypes = [vp, vp, i, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp]
     L.arucohip_mgpu_detect_streams.argtypes = [vp, vp, vp, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp]
+    L.arucohip_mgpu_set_depth.argtypes = [vp, i]
+    L.arucohip_mgpu_submit_batch.argtypes = [vp, vp, i, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp, vp]
+    L.arucohip_mgpu_submit_streams.argtypes = [vp, vp, vp, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp, vp]
+    L.arucohip_mgpu_wait.argtypes = [vp, i]
+    L.arucohip_compact_bytes.argtypes = [i, i]
+    L.arucohip_compact_bytes.restype = sz
+    L.arucohip_compact_markers.argtypes = [vp, vp, i, i, vp, i, vp]
+    L.arucohip_wait_event.argtypes = [vp, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
     return L
+
+
+def compact_bytes(nframes, cap_total):
+    """Size of the packed gather block of arucohip_compact_markers."""
+    return int(load().arucohip_compact_bytes(int(nframes), int(cap_total)))
+
+
+def compact_markers(blocks_ptr, counts_ptr, nframes, cap, dst_ptr, cap_total, stream_ptr=0):
+    """arucohip_compact_markers on device pointers (plain integers) and a HIP stream pointer."""
+    rc = load().arucohip_compact_markers(C.c_void_p(blocks_ptr), C.c_void_p(counts_ptr), int(nframes), int(cap), C.c_void_p(dst_ptr), int(cap_total),
+                                          C.c_void_p(stream_ptr))
+    if rc != OK:
+        raise ArucoHipError(rc, "arucohip_compact_markers")
 
 
 def default_params():
@@ -223,6 +246,10 @@ class Handle:
 
     def synchronize(self):
         self._chk(self.L.arucohip_synchronize(self.h))
+
+    def wait_event(self, event_ptr):
+        """The handle's next work waits for a hipEvent_t (plain integer) recorded behind the producer of the frames."""
+        self._chk(self.L.arucohip_wait_event(self.h, C.c_void_p(event_ptr)))
 
     # ---- host-buffer API
     def detect(self, gray, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128):
@@ -519,6 +546,41 @@ class MultiGpu:
         self._chk(self.L.arucohip_mgpu_detect_batch(self.m, _ptr(fr), nf, w, h, w, w * h, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
                                                     float(marker_size), int(bool(y_perp)), _ptr(out), self.cap, _ptr(n)))
         return [out[f, :n[f]].copy() for f in range(nf)]
+
+    def set_depth(self, depth):
+        self._chk(self.L.arucohip_mgpu_set_depth(self.m, int(depth)))
+
+    def submit_batch_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        """arucohip_mgpu_submit_batch; returns a job whose arrays stay alive until wait(job)."""
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf, h, w = fr.shape
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((nf, self.cap), MARKER_DTYPE)
+        n = np.zeros(nf, np.int32)
+        t = C.c_int(-1)
+        self._chk(self.L.arucohip_mgpu_submit_batch(self.m, _ptr(fr), nf, w, h, w, w * h, _ptr(Ka), _ptr(da), 0 if da is None else da.size,
+                                                    float(marker_size), int(bool(y_perp)), _ptr(out), self.cap, _ptr(n), C.byref(t)))
+        return {"ticket": t.value, "frames": fr, "out": out, "n": n, "K": Ka, "dist": da, "kind": "batch"}
+
+    def submit_streams(self, ptrs, counts, width, height, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        pa = (C.c_void_p * self.G)(*[C.c_void_p(int(x)) for x in ptrs])
+        ca = np.ascontiguousarray(counts, dtype=np.int32)
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((self.G * self.per, self.cap), MARKER_DTYPE)
+        n = np.zeros(self.G * self.per, np.int32)
+        t = C.c_int(-1)
+        self._chk(self.L.arucohip_mgpu_submit_streams(self.m, pa, _ptr(ca), width, height, width, width * height, _ptr(Ka), _ptr(da),
+                                                      0 if da is None else da.size, float(marker_size), int(bool(y_perp)), _ptr(out), self.cap, _ptr(n), C.byref(t)))
+        return {"ticket": t.value, "ptrs": pa, "counts": ca, "out": out, "n": n, "K": Ka, "dist": da, "kind": "streams"}
+
+    def wait(self, job):
+        """arucohip_mgpu_wait: per-frame marker arrays of the job (frame order for a batch, [slot][frame] for streams)."""
+        self._chk(self.L.arucohip_mgpu_wait(self.m, int(job["ticket"])))
+        out, n = job["out"], job["n"]
+        if job["kind"] == "batch":
+            return [out[f, :n[f]].copy() for f in range(len(n))]
+        ca = job["counts"]
+        return [[out[g * self.per + j, :n[g * self.per + j]].copy() for j in range(int(ca[g]))] for g in range(self.G)]
 
     def detect_streams(self, ptrs, counts, width, height, K=None, dist=None, marker_size=-1.0, y_perp=False):
         """ptrs[g] = device pointer of slot g's frames (resident on its device), counts[g] frames each."""

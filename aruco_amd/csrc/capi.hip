@@ -460,6 +460,14 @@ int arucohip_synchronize(arucohip_handle* h) {
     return ARUCOHIP_OK;
 }
 
+int arucohip_wait_event(arucohip_handle* h, void* ev) {
+    if (!h || !ev) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    // a submit forks its lane from the handle's stream (ev_submit), so one wait here orders both forms behind the producer
+    HIPCHK(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev, 0));
+    return ARUCOHIP_OK;
+}
+
 int arucohip_enable_timing(arucohip_handle* h, int on) {
     if (!h) return ARUCOHIP_E_INVALID;
     h->timing = on != 0;

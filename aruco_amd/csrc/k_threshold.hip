@@ -311,17 +311,15 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
         return make_uint4(__builtin_amdgcn_perm(v.w, v.x, rep_sel), __builtin_amdgcn_perm(v.w, v.y, rep_sel), __builtin_amdgcn_perm(v.w, v.z, rep_sel),
                           __builtin_amdgcn_perm(v.w, v.w, rep_sel));
     };
-    // halo: lane 0 fetches the dword left of the strip, lane 63 the dword right of it
+    // halo: lane 0 needs the dword left of the strip, lane 63 the dword right of it. Every lane loads a dword (the others their own first
+    // one) so that the load sits in straight-line code and is waited for PF rows later (round 3: under `if (edge lane)` it had a wait of
+    // its own that drained the prefetch queue every row); BORDER_REPLICATE in x is part of the unpack selectors.
     const int xp = lane == 0 ? x - 4 : x + 16;
-    const uint32_t hxa = (uint32_t)min(max(xp, 0), W - 4);
-    const uint32_t hsel = xp < 0 ? 0x00000000u : (xp >= W ? 0x03030303u : 0x03020100u);
+    const uint32_t hxa = edge_lane ? (uint32_t)min(max(xp, 0), W - 4) : xa;
+    const uint32_t hsel02 = xp < 0 ? 0x0C000C00u : (xp >= W ? 0x0C030C03u : SEL02), hsel13 = xp < 0 ? 0x0C000C00u : (xp >= W ? 0x0C030C03u : SEL13);
     auto load_halo = [&](int r) -> uint32_t {
-        uint32_t v = 0;
-        if (edge_lane) {
-            const uint8_t* row = src + (size_t)min(max(r, 0), H - 1) * a.row_stride;
-            v = __builtin_amdgcn_perm(0u, *(const uint32_t*)(row + hxa), hsel);
-        }
-        return v;
+        const uint8_t* row = src + (size_t)min(max(r, 0), H - 1) * a.row_stride;
+        return *(const uint32_t*)(row + hxa);
     };
     auto from_left_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false); };
     auto from_right_h = [](uint32_t v, uint32_t edge) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false); };
@@ -349,8 +347,8 @@ __device__ __forceinline__ void threshold_wide_body(const ThrArgs& a) {
                 VE[d] += __builtin_amdgcn_perm(0u, nw[d], SEL02), VO[d] += __builtin_amdgcn_perm(0u, nw[d], SEL13);
                 if (has_old) VE[d] -= __builtin_amdgcn_perm(0u, od[d], SEL02), VO[d] -= __builtin_amdgcn_perm(0u, od[d], SEL13);
             }
-            VEh += __builtin_amdgcn_perm(0u, GH[sn], SEL02), VOh += __builtin_amdgcn_perm(0u, GH[sn], SEL13);
-            if (has_old) VEh -= __builtin_amdgcn_perm(0u, GH[so], SEL02), VOh -= __builtin_amdgcn_perm(0u, GH[so], SEL13);
+            VEh += __builtin_amdgcn_perm(0u, GH[sn], hsel02), VOh += __builtin_amdgcn_perm(0u, GH[sn], hsel13);
+            if (has_old) VEh -= __builtin_amdgcn_perm(0u, GH[so], hsel02), VOh -= __builtin_amdgcn_perm(0u, GH[so], hsel13);
         }
         G[so] = load_row(r + PF);
         GH[so] = load_halo(r + PF);

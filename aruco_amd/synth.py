@@ -156,14 +156,22 @@ def frame_layout(rng, width, height, n_markers=20, side_range=(90, 220), margin=
     return out
 
 
-def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quiet=1, gen=None, cells=7, table_fn=None):
-    """Rasterise one frame (uint8 tensor HxW on `device`) for a layout from frame_layout()."""
+def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quiet=1, gen=None, cells=7, table_fn=None, clutter=False):
+    """Rasterise one frame (uint8 tensor HxW on `device`) for a layout from frame_layout(). clutter: a two-level blob texture
+    (cell size ~24 px, smooth outlines) behind the markers instead of the flat background — hundreds of long borders per frame that
+    are followed, approximated and rejected (the robustness leg of bench.py; the parity tests compare such frames with the CPU restatement)."""
     dev = torch.device(device)
     base = rng.uniform(150, 210)
     gx, gy = rng.uniform(-12, 12, size=2)
     ys = torch.linspace(-0.5, 0.5, height, device=dev)[:, None]
     xs = torch.linspace(-0.5, 0.5, width, device=dev)[None, :]
     img = (base + gx * xs + gy * ys).to(torch.float32).expand(height, width).contiguous()
+    if clutter:
+        g2 = torch.Generator(device="cpu")
+        g2.manual_seed(int(rng.randint(0, 2 ** 31 - 1)))
+        field = torch.randn((1, 1, height // 24 + 3, width // 24 + 3), generator=g2).to(dev)
+        field = torch.nn.functional.interpolate(field, size=(height, width), mode="bicubic", align_corners=False)[0, 0]
+        img = torch.where(field > 0.25, img - rng.uniform(70, 110), img)
     for mk in layout:
         black = rng.uniform(15, 45)
         white = rng.uniform(215, 245)
@@ -177,7 +185,7 @@ def render_frame(layout, width, height, rng, device="cpu", noise_sigma=1.5, quie
     return img.round().clamp(0, 255).to(torch.uint8)
 
 
-def make_stream(n_frames, width=1920, height=1080, seed=4711, n_markers=20, device="cpu", noise_sigma=1.5):
+def make_stream(n_frames, width=1920, height=1080, seed=4711, n_markers=20, device="cpu", noise_sigma=1.5, clutter=False):
     """Config-2/3/5 stream: returns (frames uint8 [N,H,W] on device, truth list per frame)."""
     rng = np.random.RandomState(seed)
     frames = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)
@@ -186,7 +194,7 @@ def make_stream(n_frames, width=1920, height=1080, seed=4711, n_markers=20, devi
         lay = frame_layout(rng, width, height, n_markers=n_markers,
                            side_range=(90 * max(width, height) / 1920.0, 220 * max(width, height) / 1920.0),
                            margin=int(60 * max(width, height) / 1920.0))
-        frames[f] = render_frame(lay, width, height, rng, device=device, noise_sigma=noise_sigma)
+        frames[f] = render_frame(lay, width, height, rng, device=device, noise_sigma=noise_sigma, clutter=clutter)
         truth.append(lay)
     return frames, truth
 

@@ -195,7 +195,8 @@ def launch_ranks(n):
 
 def stub_main(args, rank, world):
     """--stub: the launcher / rank plumbing without a GPU (CPU test of `--gpus N`): gloo, a fake step that produces marker
-    blocks, the same barrier + max-over-ranks timing and gather as the real run. Never a measurement."""
+    blocks, the same barrier + max-over-ranks timing and the same overlapped, compacted gather (aruco_amd.dist.GatherPipeline) as the
+    real run. Never a measurement."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -206,36 +207,64 @@ def stub_main(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    B = min(args.batch, 8)
+    B, depth = min(args.batch, 8), 3
     blocks = np.zeros((B, CAP), MARKER_DTYPE)
     blocks["id"][:, 0] = rank
     mt = torch.from_numpy(blocks.view(np.uint8).reshape(B, CAP * 96).copy())
     ct = torch.ones(B, dtype=torch.int32)
-    gathered = None
+    cap_total = adist.agree_capacity(int(ct.sum()), B, CAP, torch.device("cpu")) if world > 1 else B * CAP
+    gp = adist.GatherPipeline(B, CAP, cap_total, depth, "cpu") if world > 1 else None
+    last = None
 
-    def step():
+    def step(i):
         time.sleep(0.002)
-        return adist.gather_marker_blocks(mt, ct, dst=0) if world > 1 else ([mt], [ct])
+        if gp is not None:
+            gp.submit(i % depth, mt, ct)       # waits for the gather this slot carried `depth` steps ago first
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    if gp is not None:
+        gp.drain()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step()
+    for i in range(args.steps):
+        step(i)
+    if gp is not None:
+        last = gp.wait((args.steps - 1) % depth)
+        gp.drain()
     if world > 1:
         dist.barrier()
     elapsed = adist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
     if rank == 0:
-        ranks_seen = sorted(int(np.frombuffer(m.numpy().tobytes(), MARKER_DTYPE)[0]["id"]) for m in gathered[0])
-        print(json.dumps({"metric": "frames/sec at %d\u00d7%d" % (W, H), "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s",
+        ranks_seen = [0]
+        if last is not None:
+            ranks_seen = sorted(int(adist.unpack_block(blk, CAP, MARKER_DTYPE)[1][0][0]["id"]) for blk in last)
+        print(json.dumps({"metric": "frames/sec at %d×%d" % (W, H), "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-                          "data": "stub (launcher test, no GPU work)", "config": {"workload": "stub", "ranks_gathered": ranks_seen}}), flush=True)
+                          "data": "stub (launcher test, no GPU work)", "config": {"workload": "stub", "ranks_gathered": ranks_seen,
+                                                                                 "gather_bytes_per_rank_and_step": gp.bytes_per_step if gp else 0}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_leg(extra, timeout=420):
+    """One of the other BASELINE configurations as a child process of its own (a fresh HIP runtime: config 4 wants 16 hardware queues),
+    after this process has released its device memory. Returns the child's JSON line as a dict, or {"error": ...}."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-latency", "--no-legs"] + extra
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+    return json.loads(lines[-1])
 
 
 def main():
@@ -250,11 +279,13 @@ def main():
                     help="BASELINE.json config: 2 = 1080p stream no pose (headline), 3 = + per-marker solvePnP, "
                          "4 = 3840x2160 6x4 board frames + batched BoardDetector pose")
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
+    ap.add_argument("--clutter", action="store_true", help="robustness leg: textured backgrounds behind the markers (not the headline)")
     ap.add_argument("--depth", type=int, default=0,
                     help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time; default 3, "
                          "config 4: 6 (its 128-frame batches wait on a 5000-step border walk: more of them in flight fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the short legs of configs 3 / 4 / pinned H2D / clutter (extra key other_configs)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", default_hw_queues(args.config))   # before torch / HIP start; the launched ranks inherit it
@@ -304,32 +335,58 @@ def main():
         board["K"] = K0.reshape(-1)
     B = min(args.batch, args.frames)
     if board is None:
-        frames, truth = synth.make_stream(args.frames, width=W, height=H, seed=4711 + rank, device=dev)
+        frames, truth = synth.make_stream(args.frames, width=W, height=H, seed=4711 + rank, device=dev, clutter=args.clutter)
     else:
         frames, _ = synth.make_board_stream(args.frames, board["ids"], board["obj"], board["K"], width=W, height=H, seed=4711 + rank, device=dev)
         truth = [[{"id": i} for i in board["ids"]] for _ in range(args.frames)]
+    torch.cuda.synchronize()
     frames_host = None
     if args.host_frames:
         frames_host = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
         frames_host.copy_(frames)
-    handle = capi.Handle(W, H, max_batch=B, device=local_rank)
-    stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream shared by the library, its events and RCCL
-    torch.cuda.set_stream(stream)
-    handle.set_stream(stream.cuda_stream)
+    limits = None
+    if args.clutter:   # textured frames fill the walker lists an order of magnitude further than the flat stream
+        limits = capi.Limits()
+        capi.load().arucohip_default_limits(ctypes_byref(limits), W, H, B)
+        limits.triggers_per_frame *= 4
+        limits.long_walks_per_plane *= 4
+        limits.contours_per_frame *= 2
+    handle = capi.Handle(W, H, max_batch=B, device=local_rank, limits=limits)
+    # the detector runs on a stream of its own: torch's current stream (and the stream RCCL orders itself against) is a different one,
+    # so nothing the gather does can hold up a batch
+    lib_stream = torch.cuda.Stream(device=dev)
+    handle.set_stream(lib_stream.cuda_stream)
     depth = args.depth if args.depth > 0 else (6 if args.config == 4 else 3)
     outs = [torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev) for _ in range(depth)]
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
     out, cnt = outs[0], cnts[0]
-    if depth > 1:
-        handle.set_pipeline_depth(depth)      # `depth` complete workers: batch i+1's threshold runs under batch i's border following
-    tickets = [None] * depth
     K = [1400, 0, 960, 0, 1400, 540, 0, 0, 1] if args.pose else None
     dcoef = [-0.10, 0.02, 1e-3, -5e-4, 0] if args.pose else None
     msize = 0.05 if args.pose else -1.0
     nwin = max(args.frames // B, 1)
 
-    boards = []
+    def src_of(off):
+        return frames_host[off].data_ptr() if frames_host is not None else frames[off].data_ptr()   # host frames: H2D is part of the step
 
+    # ---- N > 1: the capacity of the packed gather block, agreed once between the ranks from one pass over every window of the stream
+    gp, cap_total = None, B * CAP
+    if world > 1:
+        most = 0
+        for w in range(nwin):
+            if frames_host is not None:
+                handle.detect_batch_mixed(src_of(w * B), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+            else:
+                handle.detect_batch_device(src_of(w * B), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+            handle.batch_status()
+            most = max(most, int(cnt.clamp(0, CAP).sum().item()))
+        cap_total = adist.agree_capacity(most, B, CAP, dev)
+        gp = adist.GatherPipeline(B, CAP, cap_total, depth, dev)
+    if depth > 1:
+        handle.set_pipeline_depth(depth)      # `depth` complete workers: batch i+1's threshold runs under batch i's border following
+    tickets = [None] * depth
+    slot_off = [0] * depth
+
+    boards = []
     last = {"slot": 0}
 
     def finish(slot):
@@ -340,78 +397,64 @@ def main():
         last["slot"] = slot
         if board is not None:
             boards[:] = handle.board_detect_batch(B, board["ids"], board["obj"], board["info_type"], board["K"], [0.0] * 5, 0.039)
-        if world > 1:
-            adist.gather_marker_blocks(outs[slot], cnts[slot], dst=0)
+        if gp is not None:
+            # pack + asynchronous gather on the pipeline's own stream and process group; it is waited for when this slot comes round
+            # again, `depth` steps from now. The slot's next batch may overwrite the result arrays once the packing kernel has read them.
+            ev = gp.submit(slot, outs[slot], cnts[slot])
+            lib_stream.wait_event(ev)
 
     def step(i):
         off = (i % nwin) * B
         slot = i % depth
-        src = frames_host[off].data_ptr() if frames_host is not None else frames[off].data_ptr()   # host frames: H2D is part of the step
         if depth > 1:
             if tickets[slot] is not None:
                 finish(slot)                    # the batch submitted `depth` steps ago frees its result arrays
-            tickets[slot] = handle.submit_device(src, B, W, H, outs[slot].data_ptr(), CAP, cnts[slot].data_ptr(), K=K, dist=dcoef, marker_size=msize,
+            slot_off[slot] = off
+            tickets[slot] = handle.submit_device(src_of(off), B, W, H, outs[slot].data_ptr(), CAP, cnts[slot].data_ptr(), K=K, dist=dcoef, marker_size=msize,
                                                  frames_on_device=frames_host is None)
             return
+        slot_off[0] = off
         if frames_host is not None:
-            handle.detect_batch_mixed(src, B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+            handle.detect_batch_mixed(src_of(off), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
         else:
-            handle.detect_batch_device(src, B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+            handle.detect_batch_device(src_of(off), B, W, H, out.data_ptr(), CAP, cnt.data_ptr(), K=K, dist=dcoef, marker_size=msize)
+        handle.batch_status()                   # raises on any device-side list overflow
         finish(0)
 
     def drain(nsteps):
-        """every batch still in flight completes (oldest first)"""
+        """every batch still in flight completes (oldest first), and so does every gather"""
         if depth > 1:
             for j in range(max(0, nsteps - depth), nsteps):
                 if tickets[j % depth] is not None:
                     finish(j % depth)
+        if gp is not None:
+            gp.drain()
 
     for i in range(args.warmup):
         step(i)
     drain(args.warmup)
-    if depth == 1:
-        handle.batch_status()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    handle.enable_timing(True)
+    # ---- the timed region: K steps, no per-kernel instrumentation (no events, no clock stamps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain(args.steps)                           # all K batches are complete inside the timed region
+    drain(args.steps)                           # all K batches and their gathers are complete inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if depth == 1:
-        handle.batch_status()                   # raises on any device-side list overflow
     elapsed = adist.max_over_ranks(elapsed, dev)
-    ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams over the timed steps
-    exec_ms, exec_n = handle.threshold_exec_ms()  # the threshold launches of the timed steps by the device clock (first wave in, last wave out)
-    chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
-    handle.enable_timing(False)
-    # Outside the timed region: the same kernels one batch at a time. With batches in flight a kernel's event interval also
-    # contains the time it shares the chip with the other batch's kernels; the isolated durations are what rocprofv3 shows
-    # per dispatch when nothing else runs.
-    ktimes_iso = ktimes
-    iso_exec_ms, iso_exec_n = exec_ms, exec_n
-    if depth > 1:
-        handle.enable_timing(True)
-        for i in range(3):
-            t = handle.submit_device(frames_host[0].data_ptr() if frames_host is not None else frames[0].data_ptr(), B, W, H, outs[0].data_ptr(), CAP,
-                                     cnts[0].data_ptr(), K=K, dist=dcoef, marker_size=msize, frames_on_device=frames_host is None)
-            handle.wait(t)
-        ktimes_iso = handle.kernel_times()
-        iso_exec_ms, iso_exec_n = handle.threshold_exec_ms()
-        handle.enable_timing(False)
 
-    # correctness guard outside the timed region: ids of the last step's frames are the rendered ids
-    n_host = cnts[last["slot"]].cpu().numpy()
-    arr = np.frombuffer(outs[last["slot"]].cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAP)
-    off = ((args.steps - 1) % nwin) * B
+    # ---- correctness guard, right behind the timed region and on ITS last batch: the detected ids are rendered ids
+    gslot = last["slot"]
+    n_host = cnts[gslot].cpu().numpy()
+    arr = np.frombuffer(outs[gslot].cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAP)
+    off = slot_off[gslot]
     found = 0
     for f in range(B):
-        ids = set(int(x) for x in arr[f, :min(n_host[f], CAP)]["id"])
+        ids = set(int(x) for x in arr[f, :min(max(n_host[f], 0), CAP)]["id"])
         tids = set(t["id"] for t in truth[off + f])
         if not ids <= tids:
             raise SystemExit("frame %d: detected ids %s not a subset of rendered ids" % (f, sorted(ids - tids)))
@@ -421,26 +464,69 @@ def main():
         raise SystemExit("only %d of %d rendered markers detected" % (found, rendered))
     if board is not None and sum(b["has_pose"] for b in boards) < 0.95 * B:
         raise SystemExit("board pose missing on some frames")
+    gathered = None
+    if gp is not None and rank == 0:
+        # what arrived on rank 0 for that batch: every rank's packed block, none overflowed, rank 0's own equals its result arrays
+        gathered = gp.wait(gslot)
+        tot = 0
+        for r, blk in enumerate(gathered):
+            c, fr, ovf = adist.unpack_block(blk, CAP, capi.MARKER_DTYPE)
+            if ovf:
+                raise SystemExit("rank %d: gather block overflowed its agreed capacity (%d markers)" % (r, cap_total))
+            tot += int(np.clip(c, 0, CAP).sum())
+            if r == 0:
+                for f in range(B):
+                    if fr[f] is None or fr[f].tobytes() != arr[f, :min(max(n_host[f], 0), CAP)].tobytes():
+                        raise SystemExit("gathered block of rank 0 differs from its result arrays at frame %d" % f)
+        if tot < 0.9 * rendered * world:
+            raise SystemExit("gathered markers: %d of about %d" % (tot, rendered * world))
+
+    # ---- instrumented passes, outside the timed region: per-kernel hipEvent intervals and the threshold kernel's device-clock span with
+    # the same batches in flight, then one batch at a time (what rocprofv3 shows per dispatch when nothing else runs)
+    gp_keep, gp = gp, None                      # the instrumented passes do not gather
+    handle.enable_timing(True)
+    nin = min(args.steps, 12)
+    for i in range(nin):
+        step(i)
+    drain(nin)
+    ktimes = handle.kernel_times()              # ms per launch, hipEvents on the launch streams
+    exec_ms, exec_n = handle.threshold_exec_ms()  # the threshold launches by the device clock (first wave in, last wave out)
+    chunks, per_launch = handle.batch_chunks()  # a step = `chunks` launches of every kernel, `per_launch` frames each
+    handle.enable_timing(False)
+    ktimes_iso = ktimes
+    iso_exec_ms, iso_exec_n = exec_ms, exec_n
+    if depth > 1:
+        handle.enable_timing(True)
+        for i in range(3):
+            t = handle.submit_device(src_of(0), B, W, H, outs[0].data_ptr(), CAP, cnts[0].data_ptr(), K=K, dist=dcoef, marker_size=msize,
+                                     frames_on_device=frames_host is None)
+            handle.wait(t)
+        ktimes_iso = handle.kernel_times()
+        iso_exec_ms, iso_exec_n = handle.threshold_exec_ms()
+        handle.enable_timing(False)
+    fill = handle.debug_counters() if args.clutter else None
 
     if rank == 0:
         total_frames = world * B * args.steps
         fps = total_frames / elapsed
-        # dominant kernel = the longest when a batch runs alone; with batches in flight the event intervals of the short dependent
-        # kernels are mostly waiting for wave slots the other batches' kernels hold, not work
-        dom = max(ktimes_iso, key=lambda k: ktimes_iso[k])
-        # Duration of the dominant kernel's launches inside the timed region. For the threshold kernel the device-clock span of
-        # each launch (what rocprofv3 reports per dispatch); its hipEvent interval is also printed (event_interval_ms): with
-        # batches in flight that one contains the time the dispatch queues behind the other batches' kernels.
+        # The roofline object is about the pipeline's one HBM-streaming kernel, the adaptive threshold pass: SURVEY §8d's algorithmic bytes
+        # (3 W H per frame) are that pass's traffic model. Since round 3 it is no longer the longest kernel of a batch — the border
+        # walkers are, a chain of dependent steps for which no byte figure exists; `longest_kernel` names it.
+        dom = "threshold_kernel"
+        longest = max(ktimes_iso, key=lambda k: ktimes_iso[k])
+        # Duration of its launches with the batches in flight: the device-clock span of each launch (what rocprofv3 reports per
+        # dispatch); its hipEvent interval is also printed (event_interval_ms): that one contains the time the dispatch queues behind the
+        # other batches' kernels.
         dom_ms = ktimes[dom]
         event_ms = dom_ms
-        if dom == "threshold_kernel" and exec_n > 0:
+        if exec_n > 0:
             dom_ms = exec_ms / exec_n
         achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes of the dominant kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
+        # HBM bytes of that kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
         # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
         traffic, traffic_src, pipe_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.config in (2, 3):     # the committed PMC passes are of the 1080p stream
+        if os.path.exists(tpath) and args.config in (2, 3) and not args.clutter:     # the committed PMC passes are of the 1080p stream
             try:
                 tj = json.load(open(tpath))
                 if dom in tj.get("kernels", {}):
@@ -452,52 +538,90 @@ def main():
                 traffic = None
         iso_ms = ktimes_iso.get(dom, dom_ms)
         res = {
-            "metric": "frames/sec at %d\u00d7%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec at %d×%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("3840x2160 6x4 board frames (24 markers), detect + batched BoardDetector solvePnP (config 4)" if board is not None else
                                     "1920x1080 synthetic stream, ~20 markers/frame, threshold+contour+decode+LINES"
                                     + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
-                                   + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else ""),
+                                   + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else "")
+                                   + (", textured backgrounds (robustness leg, not the headline)" if args.clutter else ""),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
                        "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth,
+                       "timed_region": "no per-kernel instrumentation; kernel times and the device-clock span come from separate passes after it",
                        "thresholded_image": "written in the hot path" if os.environ.get("ARUCOHIP_THRES_BYTES", "0") not in ("", "0") else
                        "kept as bit tiles + border lines, bytes on request (ARUCOHIP_THRES_BYTES=1 writes them in the hot path)", "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "frames sharded 1 stream/GPU"
-                       + (", RCCL gather of marker blocks per step" if world > 1 else "")},
+                       + (", packed marker blocks gathered over RCCL per step, asynchronously (own stream and process group), %d bytes per rank" % gp_keep.bytes_per_step
+                          if gp_keep is not None else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
-            # frac: SURVEY §8d recipe (3 W H bytes per frame) over the kernel's event interval in the timed region — with batches in
-            # flight that interval includes sharing the chip with the other batch. frac_isolated: the same over the kernel's
-            # duration when one batch runs alone. frac_own_bytes: the bytes the kernel itself moves (PMC) over that isolated
-            # duration. frac_pipeline: algorithmic bytes of all frames over the whole step.
+            # frac: SURVEY §8d recipe (3 W H bytes per frame) over the kernel's execution span with the batches in flight (instrumented pass).
+            # frac_isolated: the same over the kernel's duration when one batch runs alone. frac_own_bytes: the bytes the kernel itself
+            # moves (PMC) over that isolated duration. frac_pipeline: algorithmic bytes of all frames over the whole timed step.
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * per_launch, "frames_per_launch": per_launch,
                          "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4),
-                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the timed steps" % exec_n
-                         if (dom == "threshold_kernel" and exec_n > 0) else "hipEvent interval on the launch stream",
+                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the instrumented pass (%d batches in flight)" % (exec_n, depth)
+                         if exec_n > 0 else "hipEvent interval on the launch stream",
                          "event_interval_ms": round(event_ms, 4), "frac_event_interval": round(ALG_BYTES_PER_FRAME * per_launch / (event_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if event_ms > 0 else None,
                          "isolated_launch_ms": round(iso_ms, 4),
-                         "isolated_launch_ms_device_clock": round(iso_exec_ms / iso_exec_n, 4) if (dom == "threshold_kernel" and iso_exec_n > 0) else None,
+                         "isolated_launch_ms_device_clock": round(iso_exec_ms / iso_exec_n, 4) if iso_exec_n > 0 else None,
                          "frac_isolated": round(ALG_BYTES_PER_FRAME * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
                          "frac_own_bytes": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
                          "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
                          # every kernel's PMC bytes (replayed like `traffic`) over the step: how much of the peak the pipeline really moves
                          "pipeline_traffic_per_step": pipe_traffic,
-                         "frac_pipeline_own_bytes": round(pipe_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 5) if pipe_traffic else None},
+                         "frac_pipeline_own_bytes": round(pipe_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 5) if pipe_traffic else None,
+                         "longest_kernel": longest, "longest_kernel_isolated_ms": round(ktimes_iso[longest], 4),
+                         "longest_kernel_note": "a latency-bound chain of dependent border steps; SURVEY 8d defines no algorithmic bytes for it"},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_isolated": {k: round(v, 4) for k, v in ktimes_iso.items()},
         }
+        if fill is not None:
+            res["list_fill_per_frame"] = {k: (round(v / B, 1) if k != "status" else v) for k, v in fill.items()}
         if world == 1 and not args.no_cpu_baseline:
             nsample = min(32, args.frames)
             res["cpu_baseline"] = cpu_baseline(frames[:nsample].cpu().numpy())
+        frame0 = frames[0].cpu().numpy()
+        legs = world == 1 and not args.no_legs and args.config == 2 and not args.host_frames and not args.clutter
+        if (world == 1 and not args.no_latency and args.config != 4) or legs:
+            handle.set_pipeline_depth(0) if depth > 1 else None      # free the lanes' memory before the small handles / the child processes
         if world == 1 and not args.no_latency and args.config != 4:
-            handle.set_pipeline_depth(0) if depth > 1 else None      # free the lanes' memory before the small handles
-            res["latency"] = latency_leg(capi, frames[0].cpu().numpy())
+            res["latency"] = latency_leg(capi, frame0)
+        if legs:
+            # the other configurations of BASELINE.json on the same clock as the headline: short runs, each a child process of its own
+            handle.close()
+            del frames, outs, cnts, out, cnt
+            torch.cuda.empty_cache()
+            oc = {}
+            for key, extra in (("config3_fps", ["--config", "3", "--steps", "12", "--warmup", "3"]),
+                               ("config4_fps", ["--config", "4", "--steps", "12", "--warmup", "3"]),
+                               ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "6", "--warmup", "2"]),
+                               ("config2_clutter_fps", ["--clutter", "--batch", "256", "--frames", "256", "--steps", "12", "--warmup", "3"])):
+                d = run_leg(extra)
+                if "error" in d:
+                    oc[key] = None
+                    oc[key + "_error"] = d["error"]
+                else:
+                    oc[key] = d["value"]
+                    oc[key.replace("_fps", "_ms_per_step")] = d["ms_per_step"]
+                    oc[key.replace("_fps", "_steps")] = d["steps"]
+                    if key == "config2_clutter_fps":
+                        oc["config2_clutter_list_fill_per_frame"] = d.get("list_fill_per_frame")
+                        oc["config2_clutter_kernel_ms_isolated"] = d.get("kernel_ms_isolated")
+            oc["note"] = ("each a short run of `python bench.py` with the flags of that configuration in a child process (ids-subset guard as the "
+                          "headline); config2_pinned_h2d = frames start in pinned host memory, H2D inside the step; clutter = textured backgrounds, 256-frame batches")
+            res["other_configs"] = oc
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)
 
 
 if __name__ == "__main__":

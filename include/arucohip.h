@@ -122,6 +122,10 @@ const char* arucohip_last_error_string(const arucohip_handle* h);
 int arucohip_set_stream(arucohip_handle* h, void* hip_stream);
 void* arucohip_get_stream(arucohip_handle* h);
 int arucohip_synchronize(arucohip_handle* h);
+/* Frames produced on ANOTHER stream: everything the handle enqueues from now on (the next arucohip_detect_batch with device frames, the
+ * lane that takes the next arucohip_detect_batch_submit) first waits for `hip_event` (hipEvent_t passed as void*), which the producer
+ * recorded on its stream behind the last write to the frames. This is the stream-ordered alternative to synchronising the producer. */
+int arucohip_wait_event(arucohip_handle* h, void* hip_event);
 
 /* MarkerDetector::detect (markerdetector.h:102-103) for one 8-bit gray frame in HOST memory.
  * K: 9 floats row-major or NULL (no pose); dist: ndist (0,4,5,8) floats or NULL; marker_size <= 0 -> no pose.
@@ -132,8 +136,9 @@ int arucohip_detect(arucohip_handle* h, const uint8_t* gray, int width, int heig
 
 /* Same for a batch of nframes equally sized frames (frame f at frames + f*frame_stride).
  * frames_on_device != 0: `frames` is a device pointer (frames already resident in HBM). The kernels read it on the
- *                       handle's stream: frames produced on another stream must be complete before the call (synchronise
- *                       that stream, or run the handle on it with arucohip_set_stream).
+ *                       handle's stream: frames produced on another stream must be ordered before the call — record an event
+ *                       behind the producer and pass it to arucohip_wait_event, run the handle on the producer's stream
+ *                       (arucohip_set_stream), or synchronise the producer.
  * out_on_device   != 0: `out` (nframes*cap markers) and `n_out` (nframes int32) are device pointers, the call is
  *                       asynchronous on the handle's stream and reports only launch errors; otherwise host arrays and
  *                       the call returns when the results are there. */
@@ -306,6 +311,33 @@ int arucohip_mgpu_detect_batch(arucohip_mgpu* m, const uint8_t* frames, int nfra
 int arucohip_mgpu_detect_streams(arucohip_mgpu* m, const uint8_t* const* frames_dev, const int* nframes, int width, int height,
                                  size_t row_stride, size_t frame_stride, const float* K, const float* dist, int ndist,
                                  float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out);
+
+/* Asynchronous form (round 3): every device slot keeps `depth` batches in flight (arucohip_set_pipeline_depth on its handle) and has one
+ * persistent host thread, created with the detector, that submits a ticket's sub-batch as soon as a lane of its handle is free and waits
+ * for the oldest otherwise. arucohip_mgpu_set_depth(m, d): 1 <= d <= 8 tickets outstanding (default 1; rebuilds the lanes, nothing may be
+ * in flight). arucohip_mgpu_submit_batch / _submit_streams take the arguments of arucohip_mgpu_detect_batch / _detect_streams and return
+ * at once with a ticket; arucohip_mgpu_wait(ticket) blocks until every slot's sub-batch is complete and the gathered blocks are in `out` /
+ * `n_out` (same layout as the synchronous calls, which are submit + wait). Frames and output arrays of a ticket stay untouched until
+ * its wait returns; tickets are waited for in the order they were submitted. */
+int arucohip_mgpu_set_depth(arucohip_mgpu* m, int depth);
+int arucohip_mgpu_submit_batch(arucohip_mgpu* m, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                               size_t frame_stride, const float* K, const float* dist, int ndist, float marker_size,
+                               int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out, int* ticket);
+int arucohip_mgpu_submit_streams(arucohip_mgpu* m, const uint8_t* const* frames_dev, const int* nframes, int width, int height,
+                                 size_t row_stride, size_t frame_stride, const float* K, const float* dist, int ndist,
+                                 float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out, int* ticket);
+int arucohip_mgpu_wait(arucohip_mgpu* m, int ticket);
+
+/* Across PROCESSES (one rank per GPU, RCCL): the block a rank contributes to the gather. arucohip_compact_markers packs the device arrays a
+ * batch left with out_on_device (blocks_dev: nframes x cap markers, counts_dev: nframes int32) into ONE contiguous device block
+ *   { int32 total, nframes, cap_total, overflow;  int32 counts[nframes] (padded to 16 bytes);  arucohip_marker_t markers[cap_total] }
+ * with the frames' markers back to back (frame f at offset sum over j < f of min(max(counts[j], 0), cap)); overflow != 0 says that total
+ * exceeded cap_total and the tail is missing. One kernel on `hip_stream` (the current device), no handle, no host round trip;
+ * arucohip_compact_bytes gives the size of the block. At the bench's config 2 the block is a third of the fixed-capacity arrays.
+ * No reference counterpart. */
+size_t arucohip_compact_bytes(int nframes, int cap_total);
+int arucohip_compact_markers(const arucohip_marker_t* blocks_dev, const int32_t* counts_dev, int nframes, int cap, void* dst_dev,
+                             int cap_total, void* hip_stream);
 
 /* ---- OpenGL / Ogre conversions of the pose results (host arithmetic, no handle, no device work).
  * GetGLModelViewMatrix (src/utils.cpp:32-69; Marker::glGetModelViewMatrix src/marker.h:90, Board:: src/board.h:109):

@@ -67,6 +67,98 @@ def test_shard_and_gather_world2():
         assert got[f] == m[:n].tobytes()
 
 
+def _pipeline_worker(rank, world, port, n_frames, steps, depth, q):
+    """Every rank runs `steps` batches; batch t of rank r holds the fake markers of frames {t * 1000 + f}. The overlapped, compacted
+    gather (GatherPipeline, `depth` in flight) must deliver exactly what the blocking fixed-capacity gather delivers."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = adist.shard_indices(n_frames, rank, world)
+    per_rank = (n_frames + world - 1) // world          # ragged: the last rank's last frame is padding (count 0)
+
+    def batch(t):
+        blocks = np.zeros((per_rank, CAP), MARKER_DTYPE)
+        counts = np.zeros(per_rank, np.int32)
+        for j, f in enumerate(mine):
+            blocks[j], counts[j] = _fake_markers(t * 1000 + f)
+        if t == 1 and rank == 1:
+            counts[0] = -1                              # a frame that overflowed a device list travels as -1
+        return torch.from_numpy(blocks.view(np.uint8).reshape(per_rank, CAP * 96).copy()), torch.from_numpy(counts)
+
+    most = max(int(batch(t)[1].clamp(0, CAP).sum()) for t in range(steps))
+    cap_total = adist.agree_capacity(most, per_rank, CAP, torch.device("cpu"))
+    assert cap_total <= per_rank * CAP
+    gp = adist.GatherPipeline(per_rank, CAP, cap_total, depth, "cpu")
+    got, ref = {}, {}
+    for t in range(steps):
+        slot = t % depth
+        if t >= depth:                                   # the slot's previous gather is waited for `depth` steps after it started
+            blocks = gp.wait(slot)
+            if rank == 0:
+                got[t - depth] = [b.clone() for b in blocks]
+        mt, ct = batch(t)
+        gp.submit(slot, mt, ct)
+        ml, cl = adist.gather_marker_blocks(mt, ct, dst=0)   # the blocking form, same batch
+        if rank == 0:
+            ref[t] = ([m.clone() for m in ml], [c.clone() for c in cl])
+    for t in range(max(0, steps - depth), steps):
+        blocks = gp.wait(t % depth)
+        if rank == 0:
+            got[t] = [b.clone() for b in blocks]
+    gp.drain()
+    if rank == 0:
+        ok = True
+        for t in range(steps):
+            for r in range(world):
+                counts, frames, ovf = adist.unpack_block(got[t][r], CAP, MARKER_DTYPE)
+                m = np.frombuffer(ref[t][0][r].numpy().tobytes(), MARKER_DTYPE).reshape(per_rank, CAP)
+                c = ref[t][1][r].numpy()
+                ok &= not ovf and np.array_equal(counts, c)
+                for j in range(per_rank):
+                    if c[j] < 0:
+                        ok &= frames[j] is None
+                    else:
+                        ok &= frames[j].tobytes() == m[j, :c[j]].tobytes()
+        q.put((ok, gp.bytes_per_step, per_rank * CAP * 96 + per_rank * 4))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_compacted_gather_equals_the_blocking_gather():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 7, 8, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, packed, fixed = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+    assert packed <= fixed + 32      # never more than the fixed-capacity arrays plus the 16-byte header (and padding)
+    # at the bench's shape (1024 frames x 64 slots, ~20 markers per frame) the packed block is well under half of them
+    assert adist.block_bytes(1024, 1024 * 26) < 0.45 * (1024 * 64 * 96 + 1024 * 4)
+
+
+def test_pack_block_overflow_is_flagged():
+    """A block packed for fewer marker slots than the batch holds: the counts are all there, the tail is missing and the flag says so."""
+    blocks = np.zeros((3, CAP), MARKER_DTYPE)
+    counts = np.array([3, 2, 4], np.int32)
+    for f in range(3):
+        blocks[f]["id"][:counts[f]] = 10 * f + np.arange(counts[f])
+    mt = torch.from_numpy(blocks.view(np.uint8).reshape(3, CAP * 96).copy())
+    blk = adist.pack_block(mt, torch.from_numpy(counts), CAP, 6)
+    c, frames, ovf = adist.unpack_block(blk, CAP, MARKER_DTYPE)
+    assert ovf and list(c) == [3, 2, 4]
+    assert list(frames[0]["id"]) == [0, 1, 2] and list(frames[1]["id"]) == [10, 11] and list(frames[2]["id"]) == [20]
+    full = adist.pack_block(mt, torch.from_numpy(counts), CAP, 9)
+    c, frames, ovf = adist.unpack_block(full, CAP, MARKER_DTYPE)
+    assert not ovf and list(frames[2]["id"]) == [20, 21, 22, 23]
+
+
 def test_shard_indices_cover_everything():
     for n in (0, 1, 7, 8, 1024):
         for w in (1, 2, 4, 8):

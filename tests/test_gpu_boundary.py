@@ -163,8 +163,120 @@ def test_mgpu_sharding_equals_single_handle(env, flags):
         for g, cnt in enumerate([2, 2, 1]):
             for j in range(cnt):
                 assert res[g][j].tobytes() == ref[2 * g + j].tobytes()
+        # asynchronous form (round 3): two tickets outstanding, every slot keeps two batches in flight; results as the synchronous calls
+        mg.set_depth(2)
+        j0 = mg.submit_batch_host(fr)
+        j1 = mg.submit_streams(ptrs, [2, 2, 1], 1920, 1080)
+        with pytest.raises(capi.ArucoHipError) as e:            # a third ticket needs a wait first
+            mg.submit_batch_host(fr)
+        assert e.value.code == capi.E_CAPACITY
+        got0 = mg.wait(j0)
+        j2 = mg.submit_batch_host(fr[:5])                     # ragged: 2 + 2 + 1
+        res1 = mg.wait(j1)
+        got2 = mg.wait(j2)
+        with pytest.raises(capi.ArucoHipError):               # a ticket is waited for once
+            mg.wait(j2)
+        for a, b in zip(got0, ref):
+            assert a.tobytes() == b.tobytes()
+        for a, b in zip(got2, ref[:5]):
+            assert a.tobytes() == b.tobytes()
+        for g, cnt in enumerate([2, 2, 1]):
+            for j in range(cnt):
+                assert res1[g][j].tobytes() == ref[2 * g + j].tobytes()
+        mg.set_depth(1)
+        for a, b in zip(mg.detect_batch_host(fr), ref):
+            assert a.tobytes() == b.tobytes()
     finally:
         mg.close()
+
+
+def test_compact_markers_kernel_equals_the_host_packing(env):
+    """arucohip_compact_markers (the block a rank contributes to the RCCL gather) against aruco_amd.dist.pack_block on the result
+    arrays of a real batch, a block packed too small (overflow flag, counts intact) and counts that carry -1 / more than cap."""
+    capi, torch = env["capi"], env["torch"]
+    from aruco_amd import dist as adist
+    frames, _ = env["synth"].make_stream(9, width=1920, height=1080, seed=17, device="cuda")
+    CAPM = 64
+    h = capi.Handle(1920, 1080, max_batch=9)
+    try:
+        out = torch.zeros((9, CAPM * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(9, dtype=torch.int32, device="cuda")
+        h.detect_batch_device(frames.data_ptr(), 9, 1920, 1080, out.data_ptr(), CAPM, cnt.data_ptr())
+        h.batch_status()
+    finally:
+        h.close()
+    total = int(cnt.sum().item())
+    assert total > 150
+    st = torch.cuda.Stream()
+    for cap_total, counts in ((total + 7, cnt), (total - 30, cnt), (9 * CAPM, torch.tensor([3, -1, 200, 0, 5, 64, 1, 2, 70], dtype=torch.int32, device="cuda"))):
+        dst = torch.full((capi.compact_bytes(9, cap_total),), 0xAB, dtype=torch.uint8, device="cuda")
+        assert dst.numel() == adist.block_bytes(9, cap_total)
+        capi.compact_markers(out.data_ptr(), counts.data_ptr(), 9, CAPM, dst.data_ptr(), cap_total, st.cuda_stream)
+        st.synchronize()
+        ref = adist.pack_block(out.cpu(), counts.cpu(), CAPM, cap_total)
+        got = dst.cpu()
+        used = min(int(counts.clamp(0, CAPM).sum().item()), cap_total)
+        hb = adist.block_head_bytes(9)
+        assert torch.equal(got[:16 + 36], ref[:16 + 36])                        # header + counts
+        assert torch.equal(got[hb:hb + used * 96], ref[hb:hb + used * 96])      # the markers that fit
+        c, fr_, ovf = adist.unpack_block(got, CAPM, capi.MARKER_DTYPE)
+        assert ovf == (int(counts.clamp(0, CAPM).sum().item()) > cap_total)
+
+
+def test_frames_from_another_stream_ordered_by_an_event(env):
+    """The stream contract of device frames (include/arucohip.h): frames produced on another stream are ordered in front of the batch
+    with arucohip_wait_event instead of a device-wide synchronise. The producer here is slow on purpose (a chain of full-frame kernels
+    on its own stream in front of the permutation that writes the frames); without the event the batch would read frames that are still
+    being written (round 2 saw 5 of 20 markers in exactly this situation)."""
+    capi, torch = env["capi"], env["torch"]
+    frames, truth = env["synth"].make_stream(48, width=1920, height=1080, seed=23, device="cuda")
+    h = capi.Handle(1920, 1080, max_batch=48)
+    try:
+        out = torch.zeros((48, 64 * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(48, dtype=torch.int32, device="cuda")
+        h.detect_batch_device(frames.data_ptr(), 48, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        h.batch_status()
+        ref_c = cnt.cpu().numpy().copy()
+        ref = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(48, 64).copy()
+        perm = torch.randperm(48, generator=torch.Generator().manual_seed(5)).cuda()
+        staged = torch.zeros_like(frames)
+        torch.cuda.synchronize()
+        producer = torch.cuda.Stream()
+        with torch.cuda.stream(producer):
+            junk = frames.float()
+            for _ in range(40):                              # keeps the producer busy for milliseconds
+                junk = junk * 1.0001 + 0.5
+            staged.copy_(frames[perm])
+            ev = torch.cuda.Event()
+            ev.record(producer)
+        h.wait_event(ev.cuda_event)                          # no synchronise: the handle's stream waits for the producer
+        h.detect_batch_device(staged.data_ptr(), 48, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        h.batch_status()
+        c = cnt.cpu().numpy()
+        a = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(48, 64)
+        pi = perm.cpu().numpy()
+        for j in range(48):
+            assert c[j] == ref_c[pi[j]]
+            assert a[j, :c[j]].tobytes() == ref[pi[j], :ref_c[pi[j]]].tobytes()
+        assert int(c.sum()) > 900
+        # the same through submit / wait
+        h.set_pipeline_depth(2)
+        staged.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(producer):
+            junk = frames.float()
+            for _ in range(40):
+                junk = junk * 1.0001 + 0.5
+            staged.copy_(frames[perm])
+            ev2 = torch.cuda.Event()
+            ev2.record(producer)
+        h.wait_event(ev2.cuda_event)
+        t = h.submit_device(staged.data_ptr(), 48, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        h.wait(t)
+        c2 = cnt.cpu().numpy()
+        assert np.array_equal(c2, c)
+    finally:
+        h.close()
 
 
 def test_batches_in_flight_equal_synchronous_batches(env):

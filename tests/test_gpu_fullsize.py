@@ -92,7 +92,9 @@ def test_pipelined_and_permuted_batches_keep_every_frames_bytes(env):
         base, cnt = _run(env, h, fr)
         perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).cuda()
         shuffled = fr[perm].contiguous()
-        torch.cuda.synchronize()                             # include/arucohip.h: frames must be complete before the call
+        ev = torch.cuda.Event()
+        ev.record()                                          # behind the gather that writes `shuffled` on torch's stream
+        h.wait_event(ev.cuda_event)                          # include/arucohip.h: frames from another stream are ordered by an event
         arr_p, cnt_p = _run(env, h, shuffled)
         pi = perm.cpu().numpy()
         for j in range(N):
