@@ -73,7 +73,7 @@ SYMBOLS = [
     "arucohip_mgpu_device_count", "arucohip_mgpu_create", "arucohip_mgpu_destroy", "arucohip_mgpu_size", "arucohip_mgpu_handle",
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
     "arucohip_mgpu_set_depth", "arucohip_mgpu_submit_batch", "arucohip_mgpu_submit_streams", "arucohip_mgpu_wait",
-    "arucohip_compact_bytes", "arucohip_compact_markers", "arucohip_wait_event",
+    "arucohip_compact_bytes", "arucohip_compact_markers", "arucohip_wait_event", "arucohip_detect_batch_retry_overflowed",
 ]
 
 _lib = None
@@ -165,6 +165,7 @@ def load():
     L.arucohip_compact_bytes.restype = sz
     L.arucohip_compact_markers.argtypes = [vp, vp, i, i, vp, i, vp]
     L.arucohip_wait_event.argtypes = [vp, vp]
+    L.arucohip_detect_batch_retry_overflowed.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i, vp]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -344,6 +345,33 @@ class Handle:
         self._chk(self.L.arucohip_detect_batch(self.h, C.c_void_p(frames_ptr), nframes, width, height, rs, fs, 1, _ptr(Ka),
                                                _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
                                                C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1))
+
+    def retry_overflowed_device(self, frames_ptr, nframes, width, height, out_ptr, cap, n_out_ptr, K=None, dist=None, marker_size=-1.0, y_perp=False):
+        """arucohip_detect_batch_retry_overflowed on device frames / device results (after batch_status or wait returned E_OVERFLOW):
+        returns the number of frames that were run again."""
+        Ka, da = _f32(K), _f32(dist)
+        k = C.c_int(0)
+        self._chk(self.L.arucohip_detect_batch_retry_overflowed(self.h, C.c_void_p(frames_ptr), nframes, width, height, width, width * height, 1, _ptr(Ka),
+                                                                _ptr(da), 0 if da is None else da.size, float(marker_size), int(bool(y_perp)),
+                                                                C.c_void_p(out_ptr), cap, C.c_void_p(n_out_ptr), 1, C.byref(k)))
+        return k.value
+
+    def detect_batch_host_tolerant(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False, cap=128, retry=True):
+        """detect_batch_host that survives list overflows: returns (per-frame arrays or None for a frame still given up, frames retried)."""
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf, h, w = fr.shape
+        Ka, da = _f32(K), _f32(dist)
+        out = np.zeros((nf, cap), MARKER_DTYPE)
+        n = np.zeros(nf, np.int32)
+        nd = 0 if da is None else da.size
+        rc = self._chk(self.L.arucohip_detect_batch(self.h, _ptr(fr), nf, w, h, w, w * h, 0, _ptr(Ka), _ptr(da), nd, float(marker_size), int(bool(y_perp)),
+                                                    _ptr(out), cap, _ptr(n), 0), allow=(E_OVERFLOW,))
+        k = C.c_int(0)
+        first = n.copy()
+        if rc == E_OVERFLOW and retry:
+            self._chk(self.L.arucohip_detect_batch_retry_overflowed(self.h, _ptr(fr), nf, w, h, w, w * h, 0, _ptr(Ka), _ptr(da), nd, float(marker_size),
+                                                                    int(bool(y_perp)), _ptr(out), cap, _ptr(n), 0, C.byref(k)))
+        return [out[f, :n[f]].copy() if n[f] >= 0 else None for f in range(nf)], k.value, first
 
     def detect_batch_mixed(self, frames_host_ptr, nframes, width, height, out_ptr, cap, n_out_ptr, K=None, dist=None,
                            marker_size=-1.0, y_perp=False):

@@ -140,6 +140,8 @@ struct arucohip_handle {
     std::vector<arucohip_handle*> lanes;
     int next_ticket = 0;
     arucohip_handle* cur = nullptr;      // lane whose results the getters / board pose address (last waited ticket)
+    arucohip_handle* retry = nullptr;    // one-frame handle with larger lists for frames that overflowed (arucohip_detect_batch_retry_overflowed)
+    int retry_mult = 0;
     hipEvent_t ev_submit = nullptr;
     struct Pending {
         bool active = false;
@@ -235,6 +237,8 @@ static void free_all(arucohip_handle* h) {
     h->kids.clear();
     for (auto* l : h->lanes) arucohip_destroy(l);
     h->lanes.clear();
+    if (h->retry) arucohip_destroy(h->retry);
+    h->retry = nullptr;
     if (h->ev_submit) hipEventDestroy(h->ev_submit);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_thr) hipEventDestroy(h->ev_thr);
@@ -1621,6 +1625,69 @@ int arucohip_detect_batch_submit(arucohip_handle* h, const uint8_t* frames, int 
     l->pend.out = out, l->pend.n_out = n_out;
     *ticket = h->next_ticket++;
     return ARUCOHIP_OK;
+}
+
+// One bad frame must not void a batch (the reference has no limits at all, src/markerdetector.cpp:496-635): a frame whose lists overflowed
+// comes back with n = -1 and everything else is valid. This call runs exactly those frames again, one at a time, on a one-frame handle
+// whose per-frame lists are 4x (then 16x, 64x) the batch handle's, and patches their results into the caller's arrays.
+int arucohip_detect_batch_retry_overflowed(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
+                                           int frames_on_device, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
+                                           arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device, int* n_retried) {
+    if (!h || !frames || !n_out || (cap > 0 && !out) || cap < 0 || nframes < 1) return ARUCOHIP_E_INVALID;
+    if (n_retried) *n_retried = 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int32_t> n(nframes);
+    if (out_on_device)
+        HIPCHK(h, hipMemcpy(n.data(), n_out, (size_t)nframes * sizeof(int32_t), hipMemcpyDeviceToHost));
+    else
+        std::memcpy(n.data(), n_out, (size_t)nframes * sizeof(int32_t));
+    std::vector<arucohip_marker_t> tmp((size_t)std::max(cap, 1));
+    int ret = ARUCOHIP_OK;
+    for (int f = 0; f < nframes; f++) {
+        if (n[f] >= 0) continue;
+        int32_t got = 0;
+        int rc = ARUCOHIP_E_OVERFLOW;
+        for (int attempt = 0; attempt < 3 && rc == ARUCOHIP_E_OVERFLOW; attempt++) {
+            const int want = h->retry ? (attempt == 0 ? h->retry_mult : h->retry_mult * 4) : 4;
+            if (!h->retry || want != h->retry_mult) {
+                if (h->retry) arucohip_destroy(h->retry);
+                h->retry = nullptr;
+                arucohip_limits_t l = h->lim;
+                l.max_batch = 1;
+                auto grow = [&](int32_t v, long top) { return (int32_t)std::min<long>((long)v * want, top); };
+                l.triggers_per_frame = grow(l.triggers_per_frame, 1L << 22), l.contours_per_frame = grow(l.contours_per_frame, 1L << 18);
+                l.points_per_frame = grow(l.points_per_frame, 1L << 24), l.long_walks_per_plane = grow(l.long_walks_per_plane, 1L << 16);
+                l.candidates_per_frame = std::min(512, l.candidates_per_frame * 2);
+                int crc = arucohip_create_ex(&h->params, h->device, &l, &h->retry);
+                if (crc != ARUCOHIP_OK) return fail(h, crc, "creating the retry handle failed");
+                h->retry_mult = want;
+                h->retry->decoder_fn = h->decoder_fn, h->retry->decoder_user = h->decoder_user;
+                if (h->d_hrm && h->hrm_count > 0) {
+                    std::vector<uint64_t> codes(h->hrm_count);
+                    HIPCHK(h, hipMemcpy(codes.data(), h->d_hrm, codes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                    if ((crc = arucohip_set_dictionary(h->retry, h->hrm_n, h->hrm_count, codes.data(), h->hrm_tau0, h->hrm_rate))) return crc;
+                }
+            }
+            h->retry->params = h->params;
+            rc = arucohip_detect_batch(h->retry, frames + (size_t)f * frame_stride, 1, W, H, row_stride, frame_stride, frames_on_device, K, dist, ndist, marker_size,
+                                       y_perp, tmp.data(), cap, &got, 0);
+        }
+        if (rc != ARUCOHIP_OK && rc != ARUCOHIP_E_CAPACITY) {
+            if (ret == ARUCOHIP_OK) ret = fail(h, rc, h->retry ? h->retry->err.c_str() : "retry failed");
+            continue;
+        }
+        if (rc == ARUCOHIP_E_CAPACITY && ret == ARUCOHIP_OK) ret = fail(h, rc, "marker output array too small");
+        const int ncopy = std::min<int>(std::max<int>(got, 0), cap);
+        if (out_on_device) {
+            if (ncopy > 0) HIPCHK(h, hipMemcpy(out + (size_t)f * cap, tmp.data(), (size_t)ncopy * sizeof(arucohip_marker_t), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(n_out + f, &got, sizeof(int32_t), hipMemcpyHostToDevice));
+        } else {
+            if (ncopy > 0) std::memcpy(out + (size_t)f * cap, tmp.data(), (size_t)ncopy * sizeof(arucohip_marker_t));
+            n_out[f] = got;
+        }
+        if (n_retried) (*n_retried)++;
+    }
+    return ret;
 }
 
 int arucohip_detect_batch_wait(arucohip_handle* h, int ticket) {

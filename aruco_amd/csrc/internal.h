@@ -22,6 +22,7 @@ constexpr int WAVE = 64;
 constexpr int TRIG_CNT_STRIDE = 32;   // uint32 words between per-plane counters (one 128-byte line per plane)
 constexpr int TC_CDESC = 2;           // words of a plane's trig_cnt line: 0 / 1 = outer / hole start candidates,
 constexpr int TC_POOL = 3;
+constexpr int TC_STATUS = 5;          // 5 = overflow bits (StatusBits) of THIS plane: a frame whose planes carry any is reported with n = -1
 constexpr int TC_SNAP = 4;            // 4 = descriptors that existed when the late walker generations were forked            // 2 = contour descriptors, 3 = contour points allocated (per plane: no global hot counter)
 constexpr int WALK_BLOCKS = 16;       // 64-lane walker workgroups per plane
 
@@ -44,6 +45,13 @@ enum StatusBits {
     ST_MARKER_OVERFLOW = 32,
     ST_SEGMENT_ERROR = 64,
 };
+
+// a device list overflowed while working on `plane`: the batch-wide status word (the call's return code) and the plane's own word (which
+// frame to give up on: the other frames' results stay valid; the reference has no limits, src/markerdetector.cpp:496-635)
+__device__ __forceinline__ void flag_overflow(uint32_t* counters, uint32_t* trig_cnt, int plane, uint32_t bit) {
+    atomicOr(&counters[CNT_STATUS], bit);
+    atomicOr(&trig_cnt[(size_t)plane * TRIG_CNT_STRIDE + TC_STATUS], bit);
+}
 
 struct ContourDesc {
     int32_t plane;     // frame*T + t

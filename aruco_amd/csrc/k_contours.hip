@@ -103,7 +103,7 @@ __global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
             if (slot < half)
                 out[(size_t)kind * half + slot] = rec;
             else
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
         }
     };
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
                 if (slot < half)
                     out[(size_t)kind * half + slot] = s_keep[kind][j];
                 else
-                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
             }
         }
         __syncthreads();
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
                 if (base + j < half)
                     out[(size_t)kind * half + base + j] = s_keep[kind][j];
                 else
-                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
             }
         }
         __syncthreads();
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
             if (slot < half)
                 out[(size_t)kind * half + slot] = rec;
             else
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
         }
     };
     // one queued tile per lane: the tile and its five neighbours (loads only; two sets are put in flight before either is used)
@@ -580,12 +580,12 @@ __device__ __forceinline__ bool keep_border(const WalkArgs& a, int plane, bool h
     const uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
     uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], n + nck_in_pool);
     if (slot >= a.cap_cdesc) {
-        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+        flag_overflow(a.counters, a.trig_cnt, plane, ST_CDESC_OVERFLOW);
         return false;
     }
     bool ok = true;
     if (off + n + nck_in_pool > a.cap_pool) {
-        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
+        flag_overflow(a.counters, a.trig_cnt, plane, ST_POOL_OVERFLOW);
         n = 0, ok = false;  // keeps the list consistent; a zero-length contour is ignored downstream
     }
     *pool_at = (uint32_t)plane * a.cap_pool + off;
@@ -660,7 +660,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
                     uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
                     for (uint32_t c = 0; c < n / CK; c++) ck[c] = ck0[c * 64 + lane];
                 } else {
-                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                    flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
                     longw = false;
                 }
             }
@@ -676,7 +676,7 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
                         a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
                         a.gen_ring[li] = ring;
                     } else {
-                        atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_TRIG_OVERFLOW);
+                        flag_overflow(a.counters, a.trig_cnt, plane, ST_TRIG_OVERFLOW);
                     }
                 }
             }
@@ -888,7 +888,7 @@ struct QuadArgs {
     short2* pool;
     Quad* quads;
     uint32_t* counters;
-    const uint32_t* trig_cnt;
+    uint32_t* trig_cnt;
     const uint32_t* walk_scratch;   // checkpoint rings of the long walks
     uint32_t cap_cdesc;
     int cap_quads, nthr;
@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
                 q.pad_ = 0;
                 a.quads[(size_t)frame * a.cap_quads + slot] = q;
             } else {
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_QUAD_OVERFLOW);
+                flag_overflow(a.counters, a.trig_cnt, cd.plane, ST_QUAD_OVERFLOW);
             }
         }
     }
@@ -1156,6 +1156,8 @@ struct FrameArgs {
     uint32_t cap_flat;
     int32_t* ncands;
     uint32_t* counters;
+    uint32_t* trig_cnt;   // per-plane counter lines: the frame's first plane takes the frame-level overflow bits
+    int nthr;
     int cap_quads, cap_cands;
 };
 
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
         for (int i = 0; i < nq; i++) {
             if (s_rem[i]) continue;
             if (n >= a.cap_cands) {
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CAND_OVERFLOW);
+                flag_overflow(a.counters, a.trig_cnt, frame * a.nthr, ST_CAND_OVERFLOW);
                 break;
             }
             Cand c;
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
                 if (base + i < a.cap_flat)
                     a.cand_list[base + i] = ((uint32_t)frame << 16) | (uint32_t)i;
                 else
-                    atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CAND_OVERFLOW);
+                    flag_overflow(a.counters, a.trig_cnt, frame * a.nthr, ST_CAND_OVERFLOW);
             }
         }
     }
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
 
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
     FrameArgs a;
-    a.quads = b.quads, a.cands = b.cands, a.ncands = b.ncands, a.counters = b.counters;
+    a.quads = b.quads, a.cands = b.cands, a.ncands = b.ncands, a.counters = b.counters, a.trig_cnt = b.trig_cnt, a.nthr = p.nthr;
     a.cand_list = b.cand_list, a.cap_flat = b.cap_flat;
     a.cap_quads = b.cap_quads, a.cap_cands = b.cap_cands;
     hipLaunchKernelGGL(frame_candidates_kernel, dim3(nframes), dim3(64), 0, s, a);

@@ -28,6 +28,8 @@ struct FinalArgs {
     int32_t* nmarkers;
     uint32_t* counters;
     uint32_t* marker_list;
+    const uint32_t* trig_cnt;   // per-plane counter lines: TC_STATUS = overflow bits of the plane
+    int nthr;
     int cap_cands, cap_markers;
     int bx0, by0, bx1, by1;
 };
@@ -94,6 +96,11 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
             n++;
         }
         if (n > a.cap_markers) atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_MARKER_OVERFLOW);
+        // a device list overflowed while one of this frame's planes was worked on: its result may be incomplete and is given up (n = -1);
+        // every other frame of the batch is unaffected (the lists are per plane / per frame, or name the frame that did not fit)
+        uint32_t fst = 0;
+        for (int t = 0; t < a.nthr; t++) fst |= a.trig_cnt[(size_t)(frame * a.nthr + t) * TRIG_CNT_STRIDE + TC_STATUS];
+        if (fst) n = -1;
         a.nmarkers[frame] = n;   // required count; the host clamps and reports ARUCOHIP_E_CAPACITY
         // work list of the pose kernel (order across frames is irrelevant); never more than F * cap_markers entries
         const int kept = min(n, a.cap_markers);
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
 void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
     FinalArgs a;
     a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters, a.marker_list = b.marker_list;
+    a.trig_cnt = b.trig_cnt, a.nthr = p.nthr;
     a.cap_cands = b.cap_cands, a.cap_markers = b.cap_markers;
     a.bx0 = p.bx0, a.by0 = p.by0, a.bx1 = p.bx1, a.by1 = p.by1;
     hipLaunchKernelGGL(finalize_kernel, dim3(nframes), dim3(64), 0, s, a);

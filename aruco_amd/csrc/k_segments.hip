@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
         }
         if (!is_node) continue;
         if (next_key == NONE32) {   // no waypoint within the bound: cannot happen for borders that cross the grid
-            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_SEGMENT_ERROR);
+            flag_overflow(a.counters, a.trig_cnt, plane, ST_SEGMENT_ERROR);
             flag = 2, next_key = key, len = 0;
         }
         a.node[nb + i] = make_uint4(next_key, mn, len | ((uint32_t)flag << 16), NONE32);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
                 }
             }
             if (found == NONE32) {
-                atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_SEGMENT_ERROR);
+                flag_overflow(a.counters, a.trig_cnt, plane, ST_SEGMENT_ERROR);
                 found = i;
             }
         }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         const uint32_t slot = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], 1u);
         const uint32_t off = atomicAdd(&a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_POOL], total);
         if (slot >= a.cap_cdesc) {
-            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_CDESC_OVERFLOW);
+            flag_overflow(a.counters, a.trig_cnt, plane, ST_CDESC_OVERFLOW);
             continue;
         }
         ContourDesc cd;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         cd.ck_off = 0xFFFFFFFFu, cd.pad_ = 0;
         const uint32_t gslot = (uint32_t)plane * a.cap_cdesc + slot;
         if (off + total > a.cap_pool) {
-            atomicOr(&a.counters[CNT_STATUS], (uint32_t)ST_POOL_OVERFLOW);
+            flag_overflow(a.counters, a.trig_cnt, plane, ST_POOL_OVERFLOW);
             cd.n = 0;
             a.cdesc[gslot] = cd;
             continue;

@@ -31,7 +31,8 @@ enum {
     ARUCOHIP_E_UNSUPPORTED = 3,  /* a parameter value outside what the device kernels are built for (warp size > 128, adaptive block > 31,
                                     SUBPIX window > 15, locked-corner window > 31, dictionary markers beyond 8x8 / 4096 entries) */
     ARUCOHIP_E_HIP = 4,          /* HIP runtime failure, see arucohip_last_error_string */
-    ARUCOHIP_E_OVERFLOW = 5,     /* an internal device list overflowed (raise limits with arucohip_create_ex) */
+    ARUCOHIP_E_OVERFLOW = 5,     /* an internal device list overflowed for some frame(s): those have n_out = -1, the others are valid
+                                    (arucohip_detect_batch_retry_overflowed, or raise the limits with arucohip_create_ex) */
     ARUCOHIP_E_BOARD_CONFIG = 6  /* empty board configuration (boarddetector.cpp:93) */
 };
 
@@ -195,6 +196,15 @@ int arucohip_undistort(arucohip_handle* h, const uint8_t* src, int nframes, int 
                        int channels, int src_on_device, const float* K, const float* dist, int ndist, uint8_t* dst, int dst_on_device);
 /* After an asynchronous batch: synchronise and report device-side overflow / capacity conditions. */
 int arucohip_batch_status(arucohip_handle* h);
+/* Device lists are finite (arucohip_limits_t), the reference's vectors are not (src/markerdetector.cpp:496-635). When a list overflows
+ * the call returns ARUCOHIP_E_OVERFLOW, but only the frames it happened to are given up: their n_out is -1, every other frame of the batch
+ * holds its complete result. arucohip_detect_batch_retry_overflowed takes the arguments of the batch call that returned the code (after it
+ * has completed: arucohip_batch_status / _wait for device outputs) and runs the frames with n_out = -1 again, one at a time, on an internal
+ * one-frame handle whose per-frame lists are 4x (16x, 64x) larger, patching out / n_out in place; *n_retried = frames redone. */
+int arucohip_detect_batch_retry_overflowed(arucohip_handle* h, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
+                                           size_t frame_stride, int frames_on_device, const float* K, const float* dist, int ndist,
+                                           float marker_size, int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out,
+                                           int out_on_device, int* n_retried);
 /* With the environment variable ARUCOHIP_STREAMS = 2..8 a large batch is processed as that many chunks of consecutive
  * frames on separate HIP streams (default 1) that fork from and join the handle's stream, so the caller sees one
  * stream-ordered call; host frames of chunk i+1 are copied while chunk i computes. Returns the number of chunks of the

@@ -54,6 +54,22 @@ def test_shim_header_compiles_without_opencv(tmp_path):
     assert r.returncode == 1 and "Usage" in r.stderr
 
 
+def test_shim_opencv_branch_compiles_against_a_mock_opencv(tmp_path):
+    """The branch of the shim that is taken when <opencv2/core.hpp> exists (real cv::Mat / cv::InputArray / cv::Exception instead of the
+    shim's stand-ins) goes through a compiler: tests/cpp/mock_opencv/opencv2/core.hpp is the builder's own mock of the API shapes that
+    branch touches (MatStep, MatExpr from Mat::zeros, _InputArray::getMat, the five-argument cv::Exception). Both the reference-style
+    caller tests/cpp/shim_opencv_branch.cpp and tools/aruco_simple.cpp compile warning-free with it and link against the library. What
+    this does NOT check: behaviour against a real OpenCV build."""
+    inc = ["-I" + os.path.join(ROOT, "tests", "cpp", "mock_opencv"), "-I" + os.path.join(ROOT, "include")]
+    link = ["-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    for src, exe in ((os.path.join(ROOT, "tests", "cpp", "shim_opencv_branch.cpp"), "shim_cv"), (os.path.join(ROOT, "tools", "aruco_simple.cpp"), "simple_cv")):
+        out = str(tmp_path / exe)
+        r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-DARUCOHIP_USE_OPENCV"] + inc + [src, "-o", out] + link, capture_output=True, text=True)
+        assert r.returncode == 0 and "warning" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([str(tmp_path / "shim_cv")], capture_output=True, text=True)
+    assert r.returncode == 0 and "OpenCV branch" in r.stderr
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     """No CPU fallback: without libarucohip.so the product raises instead of computing anything (the oracle is test
     infrastructure and is never imported by aruco_amd)."""

@@ -377,7 +377,8 @@ def test_threshold_device_clock_span_agrees_with_the_event_interval(env):
         h.enable_timing(False)
         assert launches == 4
         clk = ms / launches
-        assert 0.1 < clk < 1.0                      # 256 frames: about 0.27 ms
-        assert abs(clk - ev) / ev < 0.10, (clk, ev)
+        assert 0.05 < clk < 1.0                     # 256 frames: about 0.15 ms (round 2: 0.27)
+        # the event interval also holds the stamp reduction launched behind the kernel (~15 us) and the two event records
+        assert -0.01 < ev - clk < 0.03, (clk, ev)
     finally:
         h.close()

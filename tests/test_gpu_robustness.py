@@ -113,3 +113,50 @@ def test_cluttered_frame_overflow_is_reported_not_silent(env):
             assert a["hole"] == b["hole"] and np.array_equal(a["pts"], b["pts"])
     finally:
         h.close()
+
+
+def test_one_cluttered_frame_does_not_void_its_batch(env):
+    """Per-frame overflow (round 3): a 32-frame batch of the synthetic stream with ONE cluttered frame in it, on a handle whose lists are
+    deliberately small. The call reports ARUCOHIP_E_OVERFLOW, the cluttered frame comes back with n = -1 and the other 31 frames carry the
+    bytes a generously sized handle returns; arucohip_detect_batch_retry_overflowed then redoes exactly that frame (host and device
+    result arrays) and it equals the large handle's result too."""
+    capi, torch = env["capi"], env["torch"]
+    frames, _ = env["synth"].make_stream(32, width=1920, height=1080, seed=77, device="cuda")
+    fr = frames.cpu().numpy().copy()
+    fr[13] = _cluttered(np.random.RandomState(5), 1080, 1920)
+    big = capi.Handle(1920, 1080, max_batch=32)
+    try:
+        ref = big.detect_batch_host(fr, cap=64)
+    finally:
+        big.close()
+    lim = capi.Limits()
+    capi.load().arucohip_default_limits(C.byref(lim), 1920, 1080, 32)
+    lim.long_walks_per_plane = 512          # the stream's frames need ~250 per plane and kind, the cluttered one thousands
+    lim.contours_per_frame = 256
+    small = capi.Handle(1920, 1080, max_batch=32, limits=lim)
+    try:
+        got, retried, first = small.detect_batch_host_tolerant(fr, cap=64, retry=False)
+        assert list(np.nonzero(first < 0)[0]) == [13] and got[13] is None
+        for f in range(32):
+            if f != 13:
+                assert got[f].tobytes() == ref[f].tobytes(), f
+        got, retried, _ = small.detect_batch_host_tolerant(fr, cap=64)
+        assert retried == 1
+        for f in range(32):
+            assert got[f].tobytes() == ref[f].tobytes(), f
+        # device frames, device results
+        dfr = torch.from_numpy(fr).cuda()
+        out = torch.zeros((32, 64 * 96), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(32, dtype=torch.int32, device="cuda")
+        small.detect_batch_device(dfr.data_ptr(), 32, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr())
+        with pytest.raises(capi.ArucoHipError) as e:
+            small.batch_status()
+        assert e.value.code == capi.E_OVERFLOW
+        assert int(cnt[13].item()) == -1 and int((cnt < 0).sum().item()) == 1
+        assert small.retry_overflowed_device(dfr.data_ptr(), 32, 1920, 1080, out.data_ptr(), 64, cnt.data_ptr()) == 1
+        c = cnt.cpu().numpy()
+        a = np.frombuffer(out.cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(32, 64)
+        for f in range(32):
+            assert a[f, :c[f]].tobytes() == ref[f].tobytes(), f
+    finally:
+        small.close()
