@@ -95,6 +95,20 @@ __device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int 
     tb_load_at<LANES>(tiles, tnx, tx0, ty0, rows, lane, b);
 }
 
+// The same for a walk in progress: s = direction that points at the PREVIOUS border pixel, so the walk is heading the other way. The block
+// is placed with the pixel 9..16 pixels from the edge it comes from (what the followers' edge tests need: 8 steps of room in every
+// direction) and 15..22 pixels from the edge it is heading for, instead of 12..19 from both: a border that keeps its direction travels
+// 6..13 pixels before the next re-centring instead of 3..10. Purely a placement: which block a lane holds never changes what it reads.
+template <int LANES>
+__device__ __forceinline__ void tb_load_dir(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, int s, uint32_t* rows, int lane, TileBlock& b) {
+    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+    // heading = -step(s): dx of direction s is +1 for E, NE, SE (0, 1, 7), -1 for NW, W, SW (3, 4, 5); dy is -1 for NE, N, NW (1, 2, 3), +1 for SW, S, SE
+    const int sdx = (0x83u >> s) & 1 ? 1 : ((0x38u >> s) & 1 ? -1 : 0), sdy = (0x0Eu >> s) & 1 ? -1 : ((0xE0u >> s) & 1 ? 1 : 0);
+    const int offx = sdx > 0 ? 15 : (sdx < 0 ? 9 : 12), offy = sdy > 0 ? 15 : (sdy < 0 ? 9 : 12);   // previous pixel to the east: heading west: far from the west edge
+    const int tx0 = min(max((x - offx) >> 3, 0), tnx - 4), ty0 = min(max((y - offy) >> 3, 0), tny - 4);
+    tb_load_at<LANES>(tiles, tnx, tx0, ty0, rows, lane, b);
+}
+
 __device__ __forceinline__ bool tb_inside(const TileBlock& b, uint32_t pos) {
     const int lx = (int)(pos & 0xFFFFu) - b.bx, ly = (int)(pos >> 16) - b.by;
     return lx >= 1 && lx <= 30 && ly >= 1 && ly <= 30;

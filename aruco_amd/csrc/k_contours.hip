@@ -510,6 +510,9 @@ __device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lan
 #ifndef PER_LANE_RELOAD
 #define PER_LANE_RELOAD 1
 #endif
+#ifndef TB_DIRECTED
+#define TB_DIRECTED 1   // re-centre a walk's block ahead of the walk instead of around it (bits_tiles.h: tb_load_dir)
+#endif
 constexpr int CHUNK = 8;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length)
 
 // Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
@@ -543,7 +546,12 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
                 if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, res = WR_BAD;
             }
-            if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+            if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) {
+                if (TB_DIRECTED)
+                    tb_load_dir<LANES>(tiles, tnx, tny, pos, s, rows, lane, blk);
+                else
+                    tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+            }
         }
         const uint32_t* rb = rows + lane - (blk.by + 1) * LANES;   // row y of the image sits at rb[y * LANES]
         const int xo = -blk.bx - 1;
@@ -926,14 +934,22 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
             int s = (int)(c >> 28);
             const int n0 = k * CK, n1 = live ? min(n0 + CK, count) : n0;
             TileBlock blk;
-            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            if (TB_DIRECTED)
+                tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, s, rows, lane, blk);
+            else
+                tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
 #pragma unroll
             for (int j = 0; j < CK; j++) {
                 if (j == CK / 2) {
                     const int lx = (int)(pos & 0xFFFFu) - blk.bx, ly = (int)(pos >> 16) - blk.by;
                     const bool near = (lx < 1 + CK / 2 && blk.bx > 0) || (lx > 30 - CK / 2 && blk.bx < maxbx) || (ly < 1 + CK / 2 && blk.by > 0) ||
                                       (ly > 30 - CK / 2 && blk.by < maxby);
-                    if (near && n0 + j < n1) tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+                    if (near && n0 + j < n1) {
+                        if (TB_DIRECTED)
+                            tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, s, rows, lane, blk);
+                        else
+                            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+                    }
                 }
                 if (n0 + j < n1) {
                     const uint32_t m = tb_mask<EMIT_LANES>(rows, lane, blk, pos);

@@ -121,7 +121,8 @@ def test_one_cluttered_frame_does_not_void_its_batch(env):
     bytes a generously sized handle returns; arucohip_detect_batch_retry_overflowed then redoes exactly that frame (host and device
     result arrays) and it equals the large handle's result too."""
     capi, torch = env["capi"], env["torch"]
-    frames, _ = env["synth"].make_stream(32, width=1920, height=1080, seed=77, device="cuda")
+    from aruco_amd import synth
+    frames, _ = synth.make_stream(32, width=1920, height=1080, seed=77, device="cuda")
     fr = frames.cpu().numpy().copy()
     fr[13] = _cluttered(np.random.RandomState(5), 1080, 1920)
     big = capi.Handle(1920, 1080, max_batch=32)
