@@ -798,13 +798,15 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     MARK(K_FRAME_CANDS);
     launch_frame_candidates(s, g, nframes, dp, b);
     MARK(K_DECODE);
-    launch_decode(s, gray_dev, g, nframes, dp, b);
+    // built-in 5x5 decoder: the cell votes and the Hamming decode of a candidate are the head of its refinement wave (one dispatch less)
+    const bool fused_cells = dp.decoder == ARUCOHIP_DECODER_FIDUCIAL_5X5;
+    launch_decode(s, gray_dev, g, nframes, dp, b, fused_cells);
     if (dp.decoder == ARUCOHIP_DECODER_USER) {
         const int rc_ = user_decode_stage(h, dp);
         if (rc_) return rc_;
     }
     MARK(K_REFINE_LINES);
-    launch_refine_lines(s, g, nframes, dp, cam, b);
+    launch_refine_lines(s, g, nframes, dp, cam, b, fused_cells);
     MARK(K_REFINE_PIXELS);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX) {
         if (dp.locked) launch_locked_corners(s, gray_dev, g, nframes, dp, b);   // markerdetector.cpp:398-399

@@ -217,9 +217,10 @@ constexpr size_t GEN_CNT_WORDS = 2 * 32 * 32;                     // words of Bu
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, int pass = 0);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
-void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
+// fused_cells: the built-in 5x5 decoder runs as the head of refine_lines_kernel (launch_refine_lines with the same flag) instead of a kernel of its own
+void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, bool fused_cells = false);
 void launch_set_decoded(hipStream_t s, const Buffers& b, uint32_t n, const int2* id_nrot_dev);
-void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
+void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b, bool fused_cells = false);
 void launch_locked_corners(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);

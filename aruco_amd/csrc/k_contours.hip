@@ -17,6 +17,7 @@
 
 #include "bits_tiles.h"
 #include "internal.h"
+#include "decode_device.h"
 
 namespace ah {
 
@@ -1166,6 +1167,8 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
 // Kernel 4: per frame — reference order, orientation, near-duplicate removal  (markerdetector.cpp:562-627)
 // ---------------------------------------------------------------------------------------------
 struct FrameArgs {
+    double* iM;           // [cap_flat][9] inverse homographies of the flat candidate list (round 3: solved here, one candidate per lane)
+    int ws;               // patch size of MarkerDetector::warp
     const Quad* quads;
     Cand* cands;
     uint32_t* cand_list;
@@ -1191,10 +1194,19 @@ __device__ __forceinline__ float quad_perimeter_i(const int16_t* x, const int16_
 
 __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
     latency_bound_priority();
-    __shared__ int16_t sx[MAXQ][4], sy[MAXQ][4];
-    __shared__ int s_cdesc[MAXQ];
-    __shared__ uint8_t s_swapped[MAXQ], s_rem[MAXQ];
-    __shared__ float s_perim[MAXQ];
+    // one LDS region, two lives: the quads of the frame while they are ranked and thinned out, then the 8x8 systems of the homography solve
+    // (decode_device.h) of up to 64 candidates at a time
+    __shared__ double s_big[HOMOGRAPHY_LDS_DOUBLES];
+    static_assert(sizeof(double) * HOMOGRAPHY_LDS_DOUBLES >= MAXQ * (8 + 8 + 4 + 1 + 1 + 4 + 2), "phase-1 arrays fit the region");
+    int16_t(*sx)[4] = (int16_t(*)[4])s_big;
+    int16_t(*sy)[4] = sx + MAXQ;
+    int* s_cdesc = (int*)(sy + MAXQ);
+    float* s_perim = (float*)(s_cdesc + MAXQ);
+    int16_t* s_map = (int16_t*)(s_perim + MAXQ);      // candidate k of the frame = ranked quad s_map[k]
+    uint8_t* s_swapped = (uint8_t*)(s_map + MAXQ);
+    uint8_t* s_rem = s_swapped + MAXQ;
+    __shared__ int s_n;
+    __shared__ uint32_t s_base;
     const int frame = blockIdx.x, lane = threadIdx.x;
     const int nq = min((int)a.counters[CNT_FIXED + frame], min(a.cap_quads, MAXQ));
     const Quad* Q = a.quads + (size_t)frame * a.cap_quads;
@@ -1252,12 +1264,14 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
                 c.qx[k] = sx[i][k], c.qy[k] = sy[i][k];
             }
             c.cdesc = s_cdesc[i], c.swapped = s_swapped[i], c.id = -1, c.nrot = 0;
+            s_map[n] = (int16_t)i;
             C[n++] = c;
         }
         a.ncands[frame] = n;
         // flat list for the decode kernels (order across frames is irrelevant)
+        uint32_t base = 0;
         if (n > 0) {
-            uint32_t base = atomicAdd(&a.counters[CNT_NCAND], (uint32_t)n);
+            base = atomicAdd(&a.counters[CNT_NCAND], (uint32_t)n);
             for (int i = 0; i < n; i++) {
                 if (base + i < a.cap_flat)
                     a.cand_list[base + i] = ((uint32_t)frame << 16) | (uint32_t)i;
@@ -1265,6 +1279,32 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
                     flag_overflow(a.counters, a.trig_cnt, frame * a.nthr, ST_CAND_OVERFLOW);
             }
         }
+        s_n = n, s_base = base;
+    }
+    __syncthreads();
+    // ---- MarkerDetector::warp's getPerspectiveTransform, inverted: one candidate per lane, 64 at a time. A lane first takes the corners
+    // of ALL its candidates into registers (at most MAXQ / 64 of them): the solve reuses the LDS they sit in.
+    const int n = s_n;
+    const uint32_t base = s_base;
+    constexpr int PER_LANE = MAXQ / WAVE;
+    int16_t qx[PER_LANE][4], qy[PER_LANE][4];
+#pragma unroll
+    for (int r = 0; r < PER_LANE; r++) {
+        const int k = r * WAVE + lane;
+        if (k < n) {
+            const int i = s_map[k];
+            for (int c = 0; c < 4; c++) qx[r][c] = sx[i][c], qy[r][c] = sy[i][c];
+        } else {
+            for (int c = 0; c < 4; c++) qx[r][c] = 0, qy[r][c] = 0;
+        }
+    }
+    __syncthreads();
+    const LaneMat A{s_big, lane}, b{s_big + 64 * 64, lane};
+#pragma unroll
+    for (int r = 0; r < PER_LANE; r++) {
+        if (r * WAVE >= n) break;                       // wave-uniform
+        const int k = r * WAVE + lane;
+        if (k < n && base + (uint32_t)k < a.cap_flat) homography_lane(qx[r], qy[r], a.ws, A, b, a.iM + (size_t)(base + (uint32_t)k) * 9);
     }
 }
 
@@ -1273,6 +1313,7 @@ void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, con
     a.quads = b.quads, a.cands = b.cands, a.ncands = b.ncands, a.counters = b.counters, a.trig_cnt = b.trig_cnt, a.nthr = p.nthr;
     a.cand_list = b.cand_list, a.cap_flat = b.cap_flat;
     a.cap_quads = b.cap_quads, a.cap_cands = b.cap_cands;
+    a.iM = b.iM, a.ws = p.warp_size;
     hipLaunchKernelGGL(frame_candidates_kernel, dim3(nframes), dim3(64), 0, s, a);
 }
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "decode_device.h"
 
 namespace ah {
 
@@ -121,95 +122,7 @@ struct DecodeArgs {
     uint8_t* patches;            // [cap_flat][ws*ws]
 };
 
-// 5a: one lane per candidate — inverse homography. The 8x8 system lives in LDS, element-major so that the 64 lanes of a
-// wave never collide on a bank (index k of lane l at k*64 + l).
-struct LaneMat {
-    double* base;
-    int lane;
-    __device__ __forceinline__ double& operator[](int k) const { return base[k * 64 + lane]; }
-};
-
-__global__ __launch_bounds__(64) void homography_kernel(DecodeArgs a) {
-    latency_bound_priority();
-    __shared__ double sA[64 * 64], sb[8 * 64];
-    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
-    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= n) return;
-    const uint32_t e = a.cand_list[idx];
-    const Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
-    LaneMat A{sA, (int)threadIdx.x}, b{sb, (int)threadIdx.x};
-    const double d = (double)(float)(a.ws - 1);
-    const double dxs[4] = {0, d, d, 0}, dys[4] = {0, 0, d, d};
-    for (int i = 0; i < 64; i++) A[i] = 0;
-    for (int i = 0; i < 4; i++) {
-        const double sx = (double)(float)cand->qx[i], sy = (double)(float)cand->qy[i], dx = dxs[i], dy = dys[i];
-        const int r0 = i * 8, r1 = (i + 4) * 8;
-        A[r0 + 0] = sx, A[r1 + 3] = sx;
-        A[r0 + 1] = sy, A[r1 + 4] = sy;
-        A[r0 + 2] = 1, A[r1 + 5] = 1;
-        A[r0 + 6] = -sx * dx;
-        A[r0 + 7] = -sy * dx;
-        A[r1 + 6] = -sx * dy;
-        A[r1 + 7] = -sy * dy;
-        b[i] = dx;
-        b[i + 4] = dy;
-    }
-    // Gaussian elimination with partial pivoting, same operation order as the oracle
-    bool ok = true;
-    for (int c = 0; c < 8 && ok; c++) {
-        int piv = c;
-        double best = fabs(A[c * 8 + c]);
-        for (int r = c + 1; r < 8; r++) {
-            double v = fabs(A[r * 8 + c]);
-            if (v > best) best = v, piv = r;
-        }
-        if (best == 0) {
-            ok = false;
-            break;
-        }
-        if (piv != c) {
-            for (int k = 0; k < 8; k++) {
-                double t = A[c * 8 + k];
-                A[c * 8 + k] = A[piv * 8 + k];
-                A[piv * 8 + k] = t;
-            }
-            double t = b[c];
-            b[c] = b[piv];
-            b[piv] = t;
-        }
-        const double inv = 1.0 / A[c * 8 + c];
-        for (int r = c + 1; r < 8; r++) {
-            const double f = A[r * 8 + c] * inv;
-            if (f == 0) continue;
-            for (int k = c; k < 8; k++) A[r * 8 + k] -= f * A[c * 8 + k];
-            b[r] -= f * b[c];
-        }
-    }
-    double m[9];
-    if (ok) {
-        for (int r = 7; r >= 0; r--) {
-            double sacc = b[r];
-            for (int k = r + 1; k < 8; k++) sacc -= A[r * 8 + k] * b[k];
-            b[r] = sacc / A[r * 8 + r];
-        }
-        for (int i = 0; i < 8; i++) m[i] = b[i];
-    } else {
-        for (int i = 0; i < 8; i++) m[i] = 0;
-    }
-    m[8] = 1.0;
-    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    det = det != 0 ? 1. / det : 0;
-    double* iM = a.iM + (size_t)idx * 9;
-    iM[0] = (m[4] * m[8] - m[5] * m[7]) * det;
-    iM[1] = (m[2] * m[7] - m[1] * m[8]) * det;
-    iM[2] = (m[1] * m[5] - m[2] * m[4]) * det;
-    iM[3] = (m[5] * m[6] - m[3] * m[8]) * det;
-    iM[4] = (m[0] * m[8] - m[2] * m[6]) * det;
-    iM[5] = (m[2] * m[3] - m[0] * m[5]) * det;
-    iM[6] = (m[3] * m[7] - m[4] * m[6]) * det;
-    iM[7] = (m[1] * m[6] - m[0] * m[7]) * det;
-    iM[8] = (m[0] * m[4] - m[1] * m[3]) * det;
-}
+// 5a (inverse homography, one candidate per lane) is the tail of frame_candidates_kernel since round 3: decode_device.h, k_contours.hip
 
 // 5b: one wavefront per candidate — gather the ws x ws patch and build its 256-bin histogram.
 // The wave takes the patch in 8x8-pixel blocks, lane = pixel of the block, GQ = 7 blocks (a block row of a 56x56 patch) in flight so that the gathers
@@ -391,21 +304,8 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     a.othr[idx] = (int)max_val;
 }
 
-// 5d: one wavefront per candidate — 7x7 cell votes on the binarised patch and the 5x5 Hamming decode
-// 5x5 code as five 5-bit rows, bit x = column x (so the dictionary words of hammDistMarker are used bit-reversed)
-__device__ __forceinline__ int hamm_rows(const uint32_t v[5]) {
-    const uint32_t words[4] = {0x01, 0x1D, 0x12, 0x0E};   // 10000, 10111, 01001, 01110 reversed
-    int dist = 0;
-#pragma unroll
-    for (int y = 0; y < 5; y++) {
-        int best = 100000;
-#pragma unroll
-        for (int p = 0; p < 4; p++) best = min(best, __popc(v[y] ^ words[p]));
-        dist += best;
-    }
-    return dist;
-}
-
+// 5d: one wavefront per candidate — 7x7 cell votes on the binarised patch and the 5x5 Hamming decode (decode_device.h). Since round 3 the
+// default pipeline runs it as the head of refine_lines_kernel; this kernel remains for callers that want the ids without the refinement.
 __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
     latency_bound_priority();
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
@@ -413,65 +313,9 @@ __global__ __launch_bounds__(64) void cells_decode_kernel(DecodeArgs a) {
     for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
         const uint32_t e = a.cand_list[idx];
         Cand* cand = a.cands + (size_t)(e >> 16) * a.cap_cands + (e & 0xFFFFu);
-        const int ws = a.ws, sw = ws / 7, thr = a.othr[idx];
-        const uint8_t* patch = a.patches + (size_t)idx * ws * ws;
-        const int half = (sw * sw) / 2;
-        bool white = false;
-        if (lane < 49) {   // cell (cy,cx): white iff more than half of its pixels exceed the Otsu threshold
-            const int cy = lane / 7, cx = lane - cy * 7;
-            int cnt = 0;
-            if (sw == 8 && (((size_t)patch | (size_t)ws) & 7) == 0) {   // default 56x56 patch: a cell row is one aligned 8-byte load
-#pragma unroll
-                for (int y = 0; y < 8; y++) {
-                    const uint2 w = *(const uint2*)(patch + (cy * 8 + y) * ws + cx * 8);
-#pragma unroll
-                    for (int b = 0; b < 4; b++) cnt += (int)((w.x >> (8 * b)) & 0xFFu) > thr, cnt += (int)((w.y >> (8 * b)) & 0xFFu) > thr;
-                }
-            } else {
-                for (int y = 0; y < sw; y++)
-                    for (int x = 0; x < sw; x++) cnt += patch[(cy * sw + y) * ws + cx * sw + x] > thr;
-            }
-            white = cnt > half;
-        }
-        const unsigned long long m = __ballot(white);   // bit cy*7+cx
-        if (lane == 0) {
-            int id = -1, nrot = 0;
-            // checkBorders: all 24 frame cells must be black
-            unsigned long long border = 0x7Full | (0x7Full << 42);
-#pragma unroll
-            for (int y = 1; y < 6; y++) border |= (1ull << (7 * y)) | (1ull << (7 * y + 6));
-            if ((m & border) == 0) {
-                uint32_t cur[5], best[5];
-#pragma unroll
-                for (int y = 0; y < 5; y++) cur[y] = (uint32_t)(m >> (7 * (y + 1) + 1)) & 31u, best[y] = cur[y];
-                int min_dist = hamm_rows(cur);
-#pragma unroll
-                for (int r = 1; r < 4; r++) {
-                    uint32_t nxt[5];   // rotate: new[i][j] = old[4-j][i]
-#pragma unroll
-                    for (int i = 0; i < 5; i++) {
-                        nxt[i] = 0;
-#pragma unroll
-                        for (int j = 0; j < 5; j++) nxt[i] |= ((cur[4 - j] >> i) & 1u) << j;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 5; i++) cur[i] = nxt[i];
-                    const int dd = hamm_rows(cur);
-                    if (dd < min_dist) {
-                        min_dist = dd, nrot = r;
-#pragma unroll
-                        for (int i = 0; i < 5; i++) best[i] = cur[i];
-                    }
-                }
-                if (min_dist == 0) {
-                    id = 0;
-#pragma unroll
-                    for (int y = 0; y < 5; y++) id |= (int)((((best[y] >> 1) & 1u) << 1) | ((best[y] >> 3) & 1u)) << (2 * (4 - y));
-                }
-            }
-            cand->id = id;
-            cand->nrot = nrot;
-        }
+        int id, nrot;
+        cells_decode_wave(a.patches + (size_t)idx * a.ws * a.ws, a.ws, a.othr[idx], lane, &id, &nrot);
+        if (lane == 0) cand->id = id, cand->nrot = nrot;
     }
 }
 
@@ -540,23 +384,23 @@ __global__ __launch_bounds__(64) void hrm_decode_kernel(DecodeArgs a, HrmArgs d)
     }
 }
 
-void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b) {
+void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, bool fused_cells) {
     DecodeArgs a;
     a.gray = gray, a.row_stride = g.row_stride, a.frame_stride = g.frame_stride, a.width = g.width, a.height = g.height;
     a.ws = p.warp_size, a.cands = b.cands, a.cap_cands = b.cap_cands;
     a.cand_list = b.cand_list, a.counters = b.counters, a.cap_flat = b.cap_flat, a.iM = b.iM, a.hist = b.hist, a.othr = b.othr, a.patches = b.patches;
     const int lane_blocks = (int)((b.cap_flat + 63) / 64);
     const int wave_blocks = (int)std::min<uint32_t>(b.cap_flat, (uint32_t)nframes * 48u);
-    hipLaunchKernelGGL(homography_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
+    // the inverse homographies are there already: frame_candidates_kernel solved them (b.iM)
     hipLaunchKernelGGL(warp_hist_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
     if (p.decoder == ARUCOHIP_DECODER_USER) return;   // the host callback decodes the patches (capi.hip: user_decode_stage)
     hipLaunchKernelGGL(otsu_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
     if (p.decoder == 1) {
         HrmArgs d{p.hrm_n, p.hrm_count, p.hrm_correction, p.hrm_codes};
         hipLaunchKernelGGL(hrm_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a, d);
-    } else {
+    } else if (!fused_cells) {
         hipLaunchKernelGGL(cells_decode_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
-    }
+    }   // else: refine_lines_kernel decodes the cells of a candidate before it refines it (launch_refine_lines)
 }
 
 // ids / rotations a host decoder returned for the first n entries of the flat candidate list

@@ -11,6 +11,7 @@
 #include <float.h>
 
 #include "internal.h"
+#include "decode_device.h"
 #include "pnp_device.h"
 
 namespace ah {
@@ -47,6 +48,10 @@ struct LinesArgs {
     const uint32_t* cand_list;   // frame << 16 | index, counters[CNT_NCAND] entries
     const uint32_t* counters;
     uint32_t cap_flat;
+    // round 3: the built-in 5x5 decoder as the head of this kernel (decode_device.h: cells_decode_wave)
+    int fused_cells, ws;
+    const uint8_t* patches;      // [cap_flat][ws * ws]
+    const int32_t* othr;         // [cap_flat] Otsu thresholds
 };
 
 struct SideSums {
@@ -91,10 +96,21 @@ __device__ static void fit_line(const SideSums& s, float line[3]) {
         line[0] = -1.f, line[1] = (float)A, line[2] = (float)C;
 }
 
-__device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int lane) {
+__device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int lane, uint32_t li) {
     const int frame = (int)(e >> 16), ci = (int)(e & 0xFFFFu);
     Cand* cand = a.cands + (size_t)frame * a.cap_cands + ci;
-    if (cand->id < 0) return;
+    int nrot_fused = 0;
+    if (a.fused_cells) {
+        // FiducidalMarkers::detect on this candidate's Otsu-thresholded patch; lane 0 knows the result and publishes it
+        int id, nrot;
+        cells_decode_wave(a.patches + (size_t)li * a.ws * a.ws, a.ws, a.othr[li], lane, &id, &nrot);
+        if (lane == 0) cand->id = id, cand->nrot = nrot;
+        id = __builtin_amdgcn_readfirstlane(id);
+        nrot_fused = __builtin_amdgcn_readfirstlane(nrot);   // the other lanes take it from the register, not from the store above
+        if (id < 0) return;
+    } else if (cand->id < 0) {
+        return;
+    }
     float out[8];
     for (int k = 0; k < 8; k++) out[k] = cand->c[k];
     if (a.do_lines) {
@@ -191,7 +207,7 @@ __device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int l
     }
     // canonical corner order: std::rotate(begin, begin + 4 - nRotations, end)
     if (lane == 0) {
-        const int nrot = cand->nrot;
+        const int nrot = a.fused_cells ? nrot_fused : cand->nrot;
         float r[8];
         for (int i = 0; i < 4; i++) {
             int srci = (i + 4 - nrot) & 3;
@@ -207,11 +223,12 @@ __global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
     latency_bound_priority();
     const int lane = threadIdx.x;
     const uint32_t nlist = min(a.counters[CNT_NCAND], a.cap_flat);
-    for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) refine_one(a, a.cand_list[li], lane);
+    for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) refine_one(a, a.cand_list[li], lane, li);
 }
 
-void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
+void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b, bool fused_cells) {
     LinesArgs a;
+    a.fused_cells = fused_cells ? 1 : 0, a.ws = p.warp_size, a.patches = b.patches, a.othr = b.othr;
     a.cands = b.cands, a.ncands = b.ncands, a.cdesc = b.cdesc, a.pool = b.pool, a.cap_cands = b.cap_cands;
     a.do_lines = p.corner_method == ARUCOHIP_CORNER_LINES;
     a.cam = cam;

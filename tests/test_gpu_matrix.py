@@ -276,3 +276,33 @@ def test_degenerate_frames(env):
         assert len(h.detect(np.zeros((17, 9), np.uint8))) == 0
     finally:
         h.close()
+
+
+def test_cluttered_stream_equals_the_oracle(env):
+    """The robustness leg of bench.py (`--clutter`: a two-level blob texture behind the 20 markers, about twice the kept borders and
+    contour points of the flat stream): 32 such 1080p frames through the HIP path as one batch equal the oracle frame by frame — ids,
+    order and count exact, LINES corners <= 1e-4 relative — and every rendered marker is found."""
+    import torch
+    from aruco_amd import synth
+    capi, orc = env["capi"], env["orc"]
+    fr, truth = synth.make_stream(32, seed=4711, device="cuda", clutter=True)
+    torch.cuda.synchronize()
+    frames = fr.cpu().numpy()
+    h = capi.Handle(1920, 1080, max_batch=32)
+    try:
+        got = h.detect_batch_host(frames, cap=64)
+        fill = h.debug_counters()
+    finally:
+        h.close()
+    assert fill["status"] == 0 and fill["contours"] / 32 > 120          # it is cluttered (the flat stream keeps ~95 borders per frame)
+    o = orc.Oracle()
+    total = 0
+    for f in range(32):
+        ref = o.detect(frames[f])
+        assert [int(m["id"]) for m in got[f]] == [m["id"] for m in ref], f
+        for a, b in zip(got[f], ref):
+            ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float)
+            assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4, f
+        assert set(t["id"] for t in truth[f]) == set(int(m["id"]) for m in got[f]), f
+        total += len(got[f])
+    assert total == 32 * 20

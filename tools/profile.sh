@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 rm -rf /tmp/p_trace /tmp/p_fetch /tmp/p_write
-ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-latency ${BENCH_ARGS:-}"
+ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-latency --no-legs ${BENCH_ARGS:-}"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --kernel-include-regex "ah::" --output-format csv -d /tmp/p_trace -- python3 $ARGS > $OUT/trace.log 2>&1
 cp /tmp/p_trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
 if [ "${PASSES:-all}" = "trace" ]; then grep -h '"metric"' $OUT/trace.log | cut -c1-400; exit 0; fi

@@ -36,8 +36,8 @@ with open(os.path.join("profiles", tag + "_pmc.csv"), "w", newline="") as f:
         short = short.split("<")[0]
         # MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of a 16-byte-per-lane streaming read; the wide threshold kernel
         # reads that way (its raw FETCH_SIZE is 0.58 x W*H per frame), every other kernel here reads 4 or 8 bytes per lane
-        wide = short == "threshold_wide_kernel"
-        short = {"threshold_strip_kernel": "threshold_kernel", "threshold_wide_kernel": "threshold_kernel",
+        wide = short in ("threshold_wide_kernel", "threshold_eo_kernel")
+        short = {"threshold_strip_kernel": "threshold_kernel", "threshold_wide_kernel": "threshold_kernel", "threshold_eo_kernel": "threshold_kernel",
                  "candidates_sparse_kernel": "candidates_kernel"}.get(short, short)
         out["kernels"][short] = {"fetch_bytes_per_launch": fe * 1024 * (2 if wide else 1), "write_bytes_per_launch": wr * 1024,
                                  "fetch_correction": "x2 (16 B / lane streaming read)" if wide else "none",
