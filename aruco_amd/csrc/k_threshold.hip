@@ -39,6 +39,7 @@ struct ThrArgs {
     int fast16;           // ... multiples of 16 and width >= 16: the 16-pixel-per-lane kernel applies
     int wide_ok;          // Tuning::threshold_wide
     int eo_ok;            // Tuning::threshold_eo
+    int eo_strips, eo_segs, eo_frames;   // the round-3 kernel's 1-D grid: strips per row, row segments per frame, frames
     uint8_t* thres;
     uint64_t* tiles;
     uint64_t* tile_bits;  // non-empty-tile bitmap (internal.h), written by the wide kernel; launch_tile_bitmap for the other paths
@@ -480,10 +481,15 @@ __device__ __forceinline__ void threshold_eo_body(const ThrArgs& a) {
     static_assert(PF >= 1 && PF <= 7, "rows of prefetch");
     constexpr int UNROLL = (RING % PF == 0) ? RING : RING * PF;   // ring slots and prefetch slots are compile-time constants inside a turn
     const int lane = threadIdx.x;
-    const int frame = blockIdx.z;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one). The strips of one row segment read the same 128-byte lines
+    // where they meet (the halo dwords): the 1-D grid is unpacked so that they are 8 apart — same XCD, same L2, dispatched back to back.
+    const int L = blockIdx.x;
+    const int strip = (L >> 3) % a.eo_strips, rest = (L & 7) | (((L >> 3) / a.eo_strips) << 3);
+    const int seg = rest % a.eo_segs, frame = rest / a.eo_segs;
+    if (frame >= a.eo_frames) return;
     const int W = a.width, H = a.height;
-    const int x = (int)blockIdx.x * WSTRIP + 16 * lane;                        // first pixel of this lane
-    const int ys = (int)blockIdx.y * SEGW, ye = min(ys + SEGW, H);
+    const int x = strip * WSTRIP + 16 * lane;                                  // first pixel of this lane
+    const int ys = seg * SEGW, ye = min(ys + SEGW, H);
     const int ye8 = (ye + 7) & ~7;
     const uint8_t* src = a.gray + (size_t)frame * a.frame_stride;
     const int plane = frame * a.nthr + a.t;
@@ -650,7 +656,7 @@ __device__ __forceinline__ void threshold_eo_body(const ThrArgs& a) {
             // which of the strip's 128 tiles hold a pixel: the start-candidate kernel only visits those (and their right / lower neighbours)
             const unsigned long long balA = __ballot(out_lane && (a0 | a1) != 0u), balB = __ballot(out_lane && (b0 | b1) != 0u);
             if (lane == 0) {
-                uint64_t* bw = a.tile_bits + ((size_t)plane * a.tny + ty) * (2 * a.nstrips) + 2 * blockIdx.x;
+                uint64_t* bw = a.tile_bits + ((size_t)plane * a.tny + ty) * (2 * a.nstrips) + 2 * strip;
                 bw[0] = balA, bw[1] = balB;
             }
         }
@@ -691,8 +697,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(THR_EO_WAVES
     if (a.stamps) {
         __builtin_amdgcn_s_waitcnt(0);   // the wave's stores have left
         const uint64_t t1 = wall_clock64();
-        if (threadIdx.x == 0) {
-            const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        // same unpacking as the body; the grid is padded to whole groups of 8 x strips and the surplus workgroups own no stamp
+        const int L = blockIdx.x;
+        const int strip = (L >> 3) % a.eo_strips, rest = (L & 7) | (((L >> 3) / a.eo_strips) << 3);
+        const int seg = rest % a.eo_segs, frame = rest / a.eo_segs;
+        if (threadIdx.x == 0 && frame < a.eo_frames) {
+            const size_t w = ((size_t)frame * a.eo_segs + seg) * a.eo_strips + strip;
             a.stamps[2 * w] = t0, a.stamps[2 * w + 1] = t1;
         }
     }
@@ -796,10 +806,13 @@ static bool launch_adpt(hipStream_t s, const ThrArgs& a, int nframes, unsigned l
 #define EO_LAUNCH(SEG_)                                                                                                               \
     do {                                                                                                                              \
         segs = (a.height + (SEG_) - 1) / (SEG_);                                                                                      \
+        ThrArgs e = a;                                                                                                                \
+        e.eo_strips = strips, e.eo_segs = segs, e.eo_frames = nframes;                                                                \
+        const long nb = (((long)strips * segs * nframes + 8L * strips - 1) / (8L * strips)) * (8L * strips);                          \
         if (a.thres)                                                                                                                  \
-            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, false>), dim3(strips, segs, nframes), blk, 0, s, a);                \
+            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, false>), dim3((unsigned)nb), blk, 0, s, e);                         \
         else                                                                                                                          \
-            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, true>), dim3(strips, segs, nframes), blk, 0, s, a);                 \
+            hipLaunchKernelGGL((threshold_eo_kernel<THR_PF, SEG_, true>), dim3((unsigned)nb), blk, 0, s, e);                          \
     } while (0)
                     if (waves128 >= 512)
                         EO_LAUNCH(128);
