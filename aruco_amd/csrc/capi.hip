@@ -34,7 +34,6 @@ Tuning read_tuning() {
     t.cand_chunks = std::max(1, geti("ARUCOHIP_CAND_CHUNKS", 16));
     t.leash = geti("ARUCOHIP_LEASH", 0);
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
-    t.far_after = geti("ARUCOHIP_FAR_AFTER", 4);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;

@@ -126,7 +126,6 @@ struct Tuning {
     int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
     int ngens = 0;
     int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
-    int far_after = 4;         // ARUCOHIP_FAR_AFTER: generations after which the walks still open are finished one per wavefront (0: never)
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies

@@ -765,107 +765,6 @@ __global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
         walk_generation<true>(a, blockIdx.x - a.gen_blocks, rows);
 }
 
-// Kernel 2c (round 3): the walks that are still open after the listed generations are the few very long borders of a batch (the outline of a
-// sheet of paper in a 4K frame: 5000 points). Packed 64 to a wave they are a chain of dependent steps that stalls every few steps: each lane
-// re-centres its own 32x32 block when it needs to, and the wave waits for whichever lane is loading (0.27 us per step measured). Here ONE
-// walk owns a wavefront: the 64 lanes together load a 128 x 64-pixel window of the tile array (one 16-byte load each) into 1.3 KB of LDS as
-// row words, ahead of the walk, and step through it in lockstep; the window lasts 30 to 100 steps, so the load latency all but leaves the
-// chain. The instruction cost per step is that of a whole wave, which is why only the stragglers come here (ARUCOHIP_FAR_AFTER).
-// Same walk, same checkpoints (every CK steps into the walk's ring), same descriptor as walk_generation.
-constexpr int FW_TX = 16, FW_TY = 8;            // window in tiles
-constexpr int FW_W = FW_TX * 8, FW_H = FW_TY * 8;
-constexpr int FW_WORDS = FW_TX / 4 + 1;         // row words + one zero word so that a 3-pixel window can always be read from two words
-
-template <bool HOLE>
-__device__ __forceinline__ void far_walk(const WalkArgs& a, uint4 st, uint32_t ring, uint32_t (*win)[FW_WORDS], int lane) {
-    const uint32_t tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
-    uint32_t pos = st.y, n = st.w & 0xFFFFu;
-    int s = (int)(st.w >> 16);
-    const int plane = (int)(ring / (2u * a.long_cap));
-    const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
-    uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
-    const uint32_t nmax = (uint32_t)a.max_contour;
-    const int maxwx = (a.tnx - FW_TX) * 8, maxwy = (a.tny - FW_TY) * 8;
-    int wx0 = 0, wy0 = 0;
-    bool have = false, walking = true;
-    int res = WR_LIMIT;
-    while (walking) {
-        const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
-        {
-            const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
-            if (2u * (uint32_t)max(ax, ay) >= nmax) {   // a closed border that gets this far from its start is longer than the size filter allows
-                res = WR_BAD;
-                break;
-            }
-        }
-        const int lx = x - wx0, ly = y - wy0;
-        const bool near = !have || (lx < 1 + CHUNK && wx0 > 0) || (lx > FW_W - 2 - CHUNK && wx0 < maxwx) || (ly < 1 + CHUNK && wy0 > 0) ||
-                          (ly > FW_H - 2 - CHUNK && wy0 < maxwy);
-        if (near) {   // wave-uniform
-            // the window goes ahead of the walk: s points at the previous pixel
-            const int sdx = (0x83u >> s) & 1 ? 1 : ((0x38u >> s) & 1 ? -1 : 0), sdy = (0x0Eu >> s) & 1 ? -1 : ((0xE0u >> s) & 1 ? 1 : 0);
-            const int offx = sdx > 0 ? FW_W - 24 : (sdx < 0 ? 16 : FW_W / 2), offy = sdy > 0 ? FW_H - 24 : (sdy < 0 ? 16 : FW_H / 2);
-            const int tx0 = min(max((x - offx) >> 3, 0), a.tnx - FW_TX), ty0 = min(max((y - offy) >> 3, 0), a.tny - FW_TY);
-            wx0 = tx0 * 8, wy0 = ty0 * 8, have = true;
-            __syncthreads();
-            const int tr = lane >> 3, tc2 = lane & 7;                       // lane: tile row tr, tile columns 2 tc2 and 2 tc2 + 1
-            const uint64_t* p = tiles + (size_t)(ty0 + tr) * a.tnx + tx0 + 2 * tc2;
-            const uint64_t t0 = p[0], t1 = p[1];
-            uint16_t* w16 = (uint16_t*)&win[0][0];
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                w16[(size_t)(tr * 8 + r) * (FW_WORDS * 2) + tc2] = (uint16_t)(((uint32_t)(t0 >> (8 * r)) & 0xFFu) | (((uint32_t)(t1 >> (8 * r)) & 0xFFu) << 8));
-            __syncthreads();
-        }
-#pragma unroll
-        for (int j = 0; j < CHUNK; j++) {
-            if (walking) {
-                if ((n & (CK - 1)) == 0 && lane == 0) ck[n / CK] = pack_ck(pos, s);
-                const int px = (int)(pos & 0xFFFFu) - wx0 - 1, py = (int)(pos >> 16) - wy0 - 1;   // top-left pixel of the 3x3 neighbourhood
-                const int w = px >> 5, sh = px & 31;
-                uint32_t t3[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) t3[k] = __builtin_amdgcn_alignbit(win[py + k][w + 1], win[py + k][w], sh) & 7u;
-                const uint32_t up = t3[0], mid = t3[1], dn = t3[2];
-                const uint32_t m = (__builtin_bitreverse32(up) >> 28) | (mid >> 2) | ((mid & 1u) << 4) | (dn << 5);
-                bool bad;
-                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
-                ++n;
-                const uint32_t npos = pos + tb_dpos(d);
-                const bool closed = npos == pos0 && pos == pos1;
-                const bool stay = bad | closed;
-                if (stay | (n >= nmax)) {
-                    walking = false;
-                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
-                }
-                if (!stay) pos = npos, s = (d + 4) & 7;
-            }
-        }
-    }
-    if (lane == 0 && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
-        uint32_t at;
-        keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
-    }
-}
-
-__global__ __launch_bounds__(64) void walker_far_kernel(WalkArgs a) {
-    latency_bound_priority();
-    __shared__ uint32_t win[FW_H][FW_WORDS];
-    const int kind = blockIdx.y, lane = threadIdx.x;
-    win[lane][FW_WORDS - 1] = 0;   // FW_H == 64 rows: the pad word of every row
-    const uint32_t count = min(a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen) * GEN_CNT_STRIDE], a.gen_cap);
-    const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap;
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const uint4 st = a.gen_state[src + i];
-        const uint32_t ring = a.gen_ring[src + i];
-        if (kind)
-            far_walk<true>(a, st, ring, win, lane);
-        else
-            far_walk<false>(a, st, ring, win, lane);
-    }
-}
-static_assert(FW_H == 64, "one pad word per lane");
-
 size_t walk_scratch_words(int nplanes, const DetectParams& p, uint32_t long_cap) {
     return (size_t)((nplanes + 7) / 8) * 8 * 2 * long_cap * ((p.max_contour + CK - 1) / CK);
 }
@@ -927,12 +826,6 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
             (void)hipEventRecord(fk.forked, s);
             (void)hipStreamWaitEvent(fk.side, fk.forked, 0);
             cur = fk.side, forked = true;
-        }
-        if (b.tune.far_after > 0 && g == b.tune.far_after + 1 && a.tnx >= FW_TX && a.tny >= FW_TY) {
-            // what is still open now is finished one walk per wavefront, to the end, in one launch (kernel 2c)
-            a.gen = g, a.gen_steps = p.max_contour;
-            hipLaunchKernelGGL(walker_far_kernel, dim3(std::min(4096, std::max(64, nplanes * 2)), 2), dim3(64), 0, cur, a);
-            break;
         }
         a.gen = g;
         a.gen_steps = g <= nsched ? kSteps[g - 1] : 1024;
