@@ -884,7 +884,8 @@ __device__ __forceinline__ void wave_argmax_first(uint32_t val, uint32_t idx, ui
 }
 
 #ifndef EMIT_LANES_N
-#define EMIT_LANES_N 32
+#define EMIT_LANES_N 64   // round 3: the whole wave emits. Round 2 kept 32 (less LDS, more waves: 0.58 against 0.67 ms one batch at a time); with the
+                          // batches in flight the vector-instruction count is what counts: 446.3k / 447.6k against 443.2k / 442.5k fps, same box, alternating
 #endif
 constexpr int EMIT_LANES = EMIT_LANES_N;   // lanes that emit points at a time (each needs a 32x32 block in LDS)
 constexpr int QP_LDS = 1024;   // points of a border kept in LDS; longer borders are scanned in HBM (their pool range)
