@@ -95,6 +95,10 @@ struct arucohip_handle {
     arucohip_decoder_fn decoder_fn = nullptr;
     void* decoder_user = nullptr;
     int2* d_user_dec = nullptr;       // [cap_flat] {id, nRotations} returned by the callback
+    uint32_t* hu_list = nullptr;      // pinned staging of the callback path: candidate list, decoder results, call order
+    size_t hu_list_bytes = 0;
+    uint8_t* hu_patches = nullptr;    // pinned staging: the canonical patches handed to the callback (+ one scratch patch)
+    size_t hu_patch_bytes = 0;
     size_t scratch_words = 0;         // capacity of buf.walk_scratch
     size_t bits_bytes = 0;
     size_t patch_bytes = 0;           // capacity of buf.patches
@@ -251,6 +255,8 @@ static void free_all(arucohip_handle* h) {
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.trig), hipFree(h->buf.gen_buf), hipFree(h->zero_block), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
     hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
+    if (h->hu_list) hipHostFree(h->hu_list);
+    if (h->hu_patches) hipHostFree(h->hu_patches);
     if (h->h_markers) hipHostFree(h->h_markers);
     if (h->h_n) hipHostFree(h->h_n);
     if (h->h_counters) hipHostFree(h->h_counters);
@@ -669,32 +675,45 @@ static int ensure_walk_scratch(arucohip_handle* h, int nplanes, const DetectPara
 static int user_decode_stage(arucohip_handle* h, const DetectParams& dp) {
     hipStream_t s = h->stream;
     const Buffers& b = h->buf;
-    uint32_t ncand = 0;
-    HIPCHK(h, hipMemcpyAsync(&ncand, b.counters + CNT_NCAND, sizeof(ncand), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    const uint32_t n = std::min(ncand, b.cap_flat);
-    if (!n) return ARUCOHIP_OK;
+    // pinned staging owned by the handle, grown on demand: the steady state of a stream of calls allocates nothing
     const size_t npx = (size_t)dp.warp_size * dp.warp_size;
-    std::vector<uint32_t> list(n);
-    std::vector<uint8_t> patches((size_t)n * npx), scratch(npx);
-    HIPCHK(h, hipMemcpyAsync(list.data(), b.cand_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(patches.data(), b.patches, patches.size(), hipMemcpyDeviceToHost, s));
+    auto pinned = [&](void** p, size_t* have, size_t need) -> int {
+        if (need <= *have) return ARUCOHIP_OK;
+        if (*p) HIPCHK(h, hipHostFree(*p));
+        *p = nullptr, *have = 0;
+        HIPCHK(h, hipHostMalloc(p, need));
+        *have = need;
+        return ARUCOHIP_OK;
+    };
+    int rc;
+    if ((rc = pinned((void**)&h->hu_list, &h->hu_list_bytes, (size_t)b.cap_flat * (sizeof(uint32_t) + sizeof(int2) + sizeof(uint32_t)) + sizeof(uint32_t)))) return rc;
+    uint32_t* list = h->hu_list;                                   // [cap_flat] frame << 16 | index
+    int2* dec = (int2*)(list + b.cap_flat);                        // [cap_flat] {id, nRotations}
+    uint32_t* order = (uint32_t*)(dec + b.cap_flat);               // [cap_flat] + the candidate count behind it
+    uint32_t* ncand_p = order + b.cap_flat;
+    HIPCHK(h, hipMemcpyAsync(ncand_p, b.counters + CNT_NCAND, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    std::vector<uint32_t> order(n);
+    const uint32_t n = std::min(*ncand_p, b.cap_flat);
+    if (!n) return ARUCOHIP_OK;
+    if ((rc = pinned((void**)&h->hu_patches, &h->hu_patch_bytes, (size_t)n * npx + npx))) return rc;
+    uint8_t* patches = h->hu_patches;
+    uint8_t* scratch = patches + (size_t)n * npx;
+    HIPCHK(h, hipMemcpyAsync(list, b.cand_list, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(patches, b.patches, (size_t)n * npx, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
     for (uint32_t i = 0; i < n; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return list[x] < list[y]; });   // frame << 16 | index
-    std::vector<int2> dec(n);
+    std::sort(order, order + n, [&](uint32_t x, uint32_t y) { return list[x] < list[y]; });   // frame << 16 | index
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t i = order[k];
-        std::memcpy(scratch.data(), patches.data() + (size_t)i * npx, npx);
+        std::memcpy(scratch, patches + (size_t)i * npx, npx);
         int nrot = 0;   // the reference leaves it uninitialised (markerdetector.cpp:354); 0 is the intent
-        const int id = h->decoder_fn(h->decoder_user, scratch.data(), dp.warp_size, &nrot);
+        const int id = h->decoder_fn(h->decoder_user, scratch, dp.warp_size, &nrot);
         dec[i] = make_int2(id < 0 ? -1 : id, nrot & 3);
     }
-    if (!h->d_user_dec) HIPCHK(h, hipMalloc((void**)&h->d_user_dec, (size_t)b.cap_flat * sizeof(int2)));
-    HIPCHK(h, hipMemcpyAsync(h->d_user_dec, dec.data(), n * sizeof(int2), hipMemcpyHostToDevice, s));
+    if (!h->d_user_dec) HIPCHK(h, hipMalloc((void**)&h->d_user_dec, (size_t)b.cap_flat * sizeof(int2)));   // once per handle
+    HIPCHK(h, hipMemcpyAsync(h->d_user_dec, dec, n * sizeof(int2), hipMemcpyHostToDevice, s));
     launch_set_decoded(s, b, n, h->d_user_dec);
-    HIPCHK(h, hipStreamSynchronize(s));   // `dec` leaves scope
+    // no synchronise: the staging belongs to the handle, and the next call that touches it synchronises the stream first (the count above)
     return ARUCOHIP_OK;
 }
 
