@@ -135,16 +135,17 @@ class GatherPipeline:
     valid until the slot's next submit), elsewhere None.
     The collective runs on a process group of its own, so it never queues behind (or in front of) the caller's barriers and reductions."""
 
-    def __init__(self, nframes, cap, cap_total, depth, device, dst=0, new_group=True):
+    def __init__(self, nframes, cap, cap_total, depth, device, dst=0, new_group=True, always_collective=False):
         self.nframes, self.cap, self.cap_total, self.depth, self.dst = nframes, cap, cap_total, depth, dst
         self.device = torch.device(device)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        self.group = dist.new_group() if (new_group and self.world > 1) else None
+        # always_collective: issue the gather also in a world of one rank (the single-GPU test of the RCCL code path)
+        self.collective = self.world > 1 or always_collective
+        self.group = dist.new_group() if (new_group and self.collective) else None
         self.on_gpu = self.device.type == "cuda"
         nbytes = block_bytes(nframes, cap_total)
-        pin = {} if self.on_gpu else {}
-        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device, **pin) for _ in range(depth)]
+        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.world)] if self.rank == dst else None
                      for _ in range(depth)]
         self.work = [None] * depth
@@ -162,11 +163,11 @@ class GatherPipeline:
                                      self.stream.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-                if self.world > 1:
+                if self.collective:
                     self.work[slot] = dist.gather(self.send[slot], self.recv[slot], dst=self.dst, group=self.group, async_op=True)
         else:
             self.send[slot].copy_(pack_block(markers_u8, counts_i32, self.cap, self.cap_total))
-            if self.world > 1:
+            if self.collective:
                 self.work[slot] = dist.gather(self.send[slot], self.recv[slot], dst=self.dst, group=self.group, async_op=True)
         return ev
 
@@ -179,7 +180,7 @@ class GatherPipeline:
             else:
                 w.wait()
             self.work[slot] = None
-        if self.world == 1:
+        if not self.collective:
             return [self.send[slot]]
         return self.recv[slot] if self.rank == self.dst else None
 

@@ -596,7 +596,7 @@ def main():
             torch.cuda.empty_cache()
             oc = {}
             for key, extra in (("config3_fps", ["--config", "3", "--steps", "12", "--warmup", "3"]),
-                               ("config4_fps", ["--config", "4", "--steps", "12", "--warmup", "3"]),
+                               ("config4_fps", ["--config", "4", "--steps", "30", "--warmup", "6"]),   # 128-frame batches, six in flight: 12 steps are two rounds
                                ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "6", "--warmup", "2"]),
                                ("config2_clutter_fps", ["--clutter", "--batch", "256", "--frames", "256", "--steps", "12", "--warmup", "3"])):
                 d = run_leg(extra)

@@ -382,3 +382,67 @@ def test_threshold_device_clock_span_agrees_with_the_event_interval(env):
         assert -0.01 < ev - clk < 0.03, (clk, ev)
     finally:
         h.close()
+
+
+def test_gather_pipeline_on_the_device_with_rccl(env):
+    """The N > 1 path of bench.py on the one GPU there is: a process group of ONE rank on backend nccl (= RCCL), the packed block of a real
+    batch built by arucohip_compact_markers on the pipeline's own stream, the asynchronous gather on its own process group, the event the
+    detector's stream waits for, three slots in flight — and what arrives equals the batch's result arrays. (Between distinct GPUs the same
+    code has not run yet; the gloo tests cover world size 2.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    capi, torch = env["capi"], env["torch"]
+    from aruco_amd import dist as adist
+    if dist.is_initialized():
+        pytest.skip("a process group exists already")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        B, CAPM, depth = 24, 64, 3
+        frames, _ = env["synth"].make_stream(B, width=1920, height=1080, seed=29, device="cuda")
+        h = capi.Handle(1920, 1080, max_batch=B)
+        try:
+            lib_stream = torch.cuda.Stream()
+            h.set_stream(lib_stream.cuda_stream)
+            h.set_pipeline_depth(depth)
+            outs = [torch.zeros((B, CAPM * 96), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+            cnts = [torch.zeros(B, dtype=torch.int32, device="cuda") for _ in range(depth)]
+            # capacity as bench.py agrees it
+            h.detect_batch_device(frames.data_ptr(), B, 1920, 1080, outs[0].data_ptr(), CAPM, cnts[0].data_ptr())
+            h.batch_status()
+            cap_total = adist.agree_capacity(int(cnts[0].clamp(0, CAPM).sum().item()), B, CAPM, dev)
+            gp = adist.GatherPipeline(B, CAPM, cap_total, depth, dev, always_collective=True)
+            assert gp.bytes_per_step < 0.6 * (B * CAPM * 96)
+            tickets = [None] * depth
+            got = []
+            for i in range(7):
+                slot = i % depth
+                if tickets[slot] is not None:
+                    h.wait(tickets[slot])
+                    ev = gp.submit(slot, outs[slot], cnts[slot])     # waits for the slot's previous gather first
+                    lib_stream.wait_event(ev)
+                tickets[slot] = h.submit_device(frames.data_ptr(), B, 1920, 1080, outs[slot].data_ptr(), CAPM, cnts[slot].data_ptr())
+            for j in range(7 - depth, 7):
+                slot = j % depth
+                h.wait(tickets[slot])
+                gp.submit(slot, outs[slot], cnts[slot])
+            gp.drain()
+            for slot in range(depth):
+                blocks = gp.wait(slot)
+                assert len(blocks) == 1
+                c, fr, ovf = adist.unpack_block(blocks[0], CAPM, capi.MARKER_DTYPE)
+                assert not ovf
+                ref_c = cnts[slot].cpu().numpy()
+                ref = np.frombuffer(outs[slot].cpu().numpy().tobytes(), dtype=capi.MARKER_DTYPE).reshape(B, CAPM)
+                assert np.array_equal(c, ref_c) and int(ref_c.sum()) > 400
+                for f in range(B):
+                    assert fr[f].tobytes() == ref[f, :ref_c[f]].tobytes()
+        finally:
+            h.close()
+    finally:
+        dist.destroy_process_group()

@@ -524,10 +524,22 @@ def test_threshold_wide_kernel_strip_edges(env):
             g = np.kron(base, np.ones((8, 8), np.float32))[:hgt, :wid] + rng.randint(-20, 21, size=(hgt, wid))
             g = np.clip(g, 0, 255).astype(np.uint8)
             if wid >= 32 and hgt >= 32:
-                for block, c in ((7, 7.0), (3, 2.0), (5, -3.0), (9, 11.5)):
+                # 7x7 blocks take the round-3 kernel (test constants folded into the column sums: every sign and size of C matters; |C| > 200
+                # falls back to the round-2 kernel), the other block sizes the round-2 one
+                for block, c in ((7, 7.0), (3, 2.0), (5, -3.0), (9, 11.5), (7, -30.5), (7, -3.0), (7, 0.0), (7, 0.5), (7, 13.9), (7, 100.0),
+                                 (7, 200.0), (7, 201.0), (7, -200.0), (7, 250.0)):
                     got = h.threshold(g, capi.THRES_ADPT, block, c)
                     exp = orc.adaptive_threshold(g, block, c)
                     assert np.array_equal(got, exp), (wid, hgt, block, c, int((got != exp).sum()))
+        # extremes of the sums: all-black, all-white and a hard checkerboard, with the constants that push the folded offsets both ways
+        for fill in ("black", "white", "checker"):
+            g = np.zeros((96, 1040), np.uint8) if fill == "black" else np.full((96, 1040), 255, np.uint8)
+            if fill == "checker":
+                g = (((np.arange(96)[:, None] // 3 + np.arange(1040)[None, :] // 5) % 2) * 255).astype(np.uint8)
+            for c in (7.0, -7.0, 0.0, 199.0, -199.0):
+                got = h.threshold(g, capi.THRES_ADPT, 7, c)
+                exp = orc.adaptive_threshold(g, 7, c)
+                assert np.array_equal(got, exp), (fill, c, int((got != exp).sum()))
         for (wid, hgt) in ((1040, 131), (2064, 137)):
             img = blob_image(rng, hgt, wid, 5)
             g = np.where(img > 0, 40, 200).astype(np.uint8)       # gray frame whose threshold bands are the blob borders
