@@ -847,32 +847,24 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
 // ---------------------------------------------------------------------------------------------
 // Wave reductions on the DPP network (no LDS crossbar trips): butterfly inside each row of 16 lanes, then row
 // broadcasts; the result is read from lane 63.
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v, int ctrl, int row_mask) {
-    switch (ctrl) {   // the control word must be an immediate
-        case 0xB1: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-        case 0x4E: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-        case 0x141: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-        case 0x140: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
-        case 0x142: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
-        default: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
-    }
-}
+// max / min of the wave on the DPP network with the shuffle folded into the operation (v_max_u32_dpp: one instruction per step; written as
+// "move with DPP, then max" the compiler keeps two). Rows that a row_bcast step does not address keep their value.
+#define DPP_FOLD(op, v)                                                                                         \
+    asm volatile("s_nop 4\n\t" /* the compiler does not see a DPP read here: cover the VGPR-write (2) and VALU-EXEC-write (5) wait states */ \
+                 op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"             \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                 \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                      \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
+                 "s_nop 1"                                                                                      \
+                 : "+v"(v))
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = max(v, dpp_u32(v, v, 0xB1, 0xF));
-    v = max(v, dpp_u32(v, v, 0x4E, 0xF));
-    v = max(v, dpp_u32(v, v, 0x141, 0xF));
-    v = max(v, dpp_u32(v, v, 0x140, 0xF));
-    v = max(v, dpp_u32(v, v, 0x142, 0xA));
-    v = max(v, dpp_u32(v, v, 0x143, 0xC));
+    DPP_FOLD("v_max_u32_dpp", v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = min(v, dpp_u32(v, v, 0xB1, 0xF));
-    v = min(v, dpp_u32(v, v, 0x4E, 0xF));
-    v = min(v, dpp_u32(v, v, 0x141, 0xF));
-    v = min(v, dpp_u32(v, v, 0x140, 0xF));
-    v = min(v, dpp_u32(v, v, 0x142, 0xA));
-    v = min(v, dpp_u32(v, v, 0x143, 0xC));
+    DPP_FOLD("v_min_u32_dpp", v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // argmax with first-maximum tie break: every lane brings its best (value, position), positions are unique;
