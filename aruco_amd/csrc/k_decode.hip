@@ -148,39 +148,76 @@ constexpr int HLANES = WAVE / HCOPIES;            // lanes that share a copy
 constexpr uint32_t XCD_RUN = XCD_RUN_N;           // consecutive candidates per XCD in warp_hist_kernel (1: plain round-robin)
 constexpr int GQ = GQ_N;                          // 8x8 patch blocks (wave-gathers) in flight
 static_assert(HWCOPIES * HWPITCH <= HCOPIES * HPITCH, "both layouts share the array");
-__global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
-    latency_bound_priority();
-    __shared__ uint32_t hist[HCOPIES * HPITCH];
-    __shared__ double siM[9];
-    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
-    const int lane = threadIdx.x;
+// One pixel of the patch: the source position exactly as cv::warpPerspective forms it from the row terms (X0, Y0, W0) and the column terms
+// (ax, bx, cx), nearest neighbour, BORDER_CONSTANT 0, cvRound = round-half-even. cv::warpPerspective forms Wd = 1/W (correctly rounded),
+// fX = X*Wd, cvRound(fX). The full IEEE division is the most expensive part of the pixel, so the reciprocal is first taken from
+// v_rcp_f64 + Newton steps; the rounded integers can only differ from the reference's when fX or fY lies within the reciprocal's error
+// (times the coordinate) of a rounding boundary, and every pixel within 1e-6 of one takes the exact path (so does a NaN: the compares
+// are false). FAST (the 56 x 56 patch of a frame below 4 GB): one Newton step (v_rcp_f64 is good to 2^-24 or so, one step squares that: 1e-11 of
+// a pixel at coordinate 4000), no range test (|f| >= 2^31 saturates the conversion and lands outside the frame on both paths) and 32-bit offsets.
+template <bool FAST>
+__device__ __forceinline__ uint8_t warp_gather(const uint8_t* src, size_t row_stride, int W, int H, double X0, double Y0, double W0, double ax, double bx,
+                                               double cx, bool inside) {
+    const double Wq = W0 + cx, nx = X0 + ax, ny = Y0 + bx;
+    double r = __builtin_amdgcn_rcp(Wq);
+    r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+    if (!FAST) r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
+    double fX = nx * r, fY = ny * r;
+    bool sure = (int)(fabs(__builtin_amdgcn_fract(fX) - 0.5) > 1e-6) & (int)(fabs(__builtin_amdgcn_fract(fY) - 0.5) > 1e-6);   // no short circuit: two compares, one scalar and
+    if (!FAST) sure = sure && fabs(fX) < 1e9 && fabs(fY) < 1e9;
+    if (!sure) {
+        const double Wd = Wq != 0 ? 1. / Wq : 0;
+        fX = fmax((double)INT_MIN, fmin((double)INT_MAX, nx * Wd));
+        fY = fmax((double)INT_MIN, fmin((double)INT_MAX, ny * Wd));
+    }
+    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+    uint8_t v = 0;
+    if (FAST) {
+        if ((int)((uint32_t)X < (uint32_t)W) & (int)((uint32_t)Y < (uint32_t)H)) v = src[(uint32_t)Y * (uint32_t)row_stride + (uint32_t)X];
+    } else {
+        if (inside && X >= 0 && X < W && Y >= 0 && Y < H) v = src[(size_t)Y * row_stride + X];
+    }
+    return v;
+}
+
+// WS = 56 (the reference's default markerWarpSize, src/markerdetector.cpp:246): a patch is 7 x 7 blocks, a step of the loop is one block row, so the
+// column terms of the seven blocks are formed once per candidate and the row terms once per block row, and no pixel needs a bounds test (round 3:
+// the stream is bound by vector-instruction issue, and these were a third of the kernel's). WS = 0: any size, everything per pixel.
+template <int WS>
+__device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const uint32_t idx, uint32_t* hist, const double* siM, const int lane) {
+    const uint32_t e = a.cand_list[idx];
+    const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
     const int W = a.width, H = a.height;
-    // Workgroups are dealt round-robin over the 8 XCDs. The candidate list is ordered by frame, and the candidates of a marker (its border, the
-    // outline of its quiet zone) sample the same pixels: XCD_RUN consecutive list entries go to one XCD, so that its L2 serves the second
-    // candidate's lines instead of HBM.
-    const uint32_t nslots = ((n + 8 * XCD_RUN - 1) / (8 * XCD_RUN)) * (8 * XCD_RUN);
-    for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
-        uint32_t idx = b;
-        if (XCD_RUN > 1) {
-            const uint32_t xcd = b & 7u, r = b >> 3;
-            idx = ((r / XCD_RUN) * 8u + xcd) * XCD_RUN + (r % XCD_RUN);
+    const int ws = WS ? WS : a.ws, npx = ws * ws;
+    const bool bytes = HLANES * ((ws + 7) / 8) * ((ws + 7) / 8) < 256;   // pixels a copy can see: a byte counter must hold them
+    uint8_t* patch = a.patches + (size_t)idx * npx;
+    uint32_t* myhist = bytes ? hist + (lane / HLANES) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
+    const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
+    // The 64 lanes of a gather take an 8x8 block of patch pixels (lane = 8 * row + column inside the block), GQ blocks in
+    // flight. A gather costs about as much as the number of distinct 128-byte lines it touches: a patch ROW of a rotated
+    // marker crosses 56 image rows, an 8x8 block of the patch covers about 21 x 21 source pixels whatever the rotation.
+    const int bxl = lane & 7, byl = lane >> 3;
+    if (WS == 8 * GQ) {
+        double ax[GQ], bx[GQ], cx[GQ];
+#pragma unroll
+        for (int q = 0; q < GQ; q++) {
+            const int x = q * 8 + bxl;
+            ax[q] = m0 * x, bx[q] = m3 * x, cx[q] = m6 * x;
         }
-        if (idx >= n) continue;
-        __syncthreads();
-        const uint32_t e = a.cand_list[idx];
-        const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
-        for (int i = lane; i < HCOPIES * HPITCH; i += WAVE) hist[i] = 0;
-        const bool bytes = HLANES * ((a.ws + 7) / 8) * ((a.ws + 7) / 8) < 256;   // pixels a copy can see: a byte counter must hold them
-        if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
-        __syncthreads();
-        const int ws = a.ws, npx = ws * ws;
-        uint8_t* patch = a.patches + (size_t)idx * npx;
-        uint32_t* myhist = bytes ? hist + (lane / HLANES) * HPITCH : hist + (lane & (HWCOPIES - 1)) * HWPITCH;
-        const double m0 = siM[0], m1 = siM[1], m2 = siM[2], m3 = siM[3], m4 = siM[4], m5 = siM[5], m6 = siM[6], m7 = siM[7], m8 = siM[8];
-        // The 64 lanes of a gather take an 8x8 block of patch pixels (lane = 8 * row + column inside the block), four blocks in
-        // flight. A gather costs about as much as the number of distinct 128-byte lines it touches: a patch ROW of a rotated
-        // marker crosses 56 image rows, an 8x8 block of the patch covers about 21 x 21 source pixels whatever the rotation.
-        const int bxl = lane & 7, byl = lane >> 3;
+        uint8_t* prow = patch + byl * WS + bxl;
+        for (int BY = 0; BY < GQ; BY++) {
+            const int y = BY * 8 + byl;
+            const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
+            uint8_t v[GQ];
+#pragma unroll
+            for (int q = 0; q < GQ; q++) v[q] = warp_gather<true>(src, a.row_stride, W, H, X0, Y0, W0, ax[q], bx[q], cx[q], true);
+#pragma unroll
+            for (int q = 0; q < GQ; q++) {
+                prow[BY * 8 * WS + q * 8] = v[q];
+                atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
+            }
+        }
+    } else {
         const int nb = (ws + 7) >> 3, nblocks = nb * nb;
         for (int b0 = 0; b0 < nblocks; b0 += GQ) {
             uint8_t v[GQ];
@@ -190,28 +227,7 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
                 const int bi = b0 + q, BY = bi / nb, BX = bi - BY * nb;
                 const int x = BX * 8 + bxl, y = BY * 8 + byl;
                 px[q] = x, py[q] = (bi < nblocks && x < ws && y < ws) ? y : -1;
-                // nearest-neighbour gather (BORDER_CONSTANT 0), cvRound = round-half-even. cv::warpPerspective forms
-                // Wd = 1/W (correctly rounded), fX = X*Wd, cvRound(fX). The full IEEE division is the most expensive
-                // part of the pixel, so the reciprocal is first taken from v_rcp_f64 + two Newton steps (a few ulp);
-                // the rounded integers can only differ from the reference's when fX or fY lies within ~1e-11 of a
-                // rounding boundary, and every pixel within 1e-6 of one (or out of range) takes the exact path.
-                const double ax = m0 * x, bx = m3 * x, cx = m6 * x;
-                const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
-                const double Wq = W0 + cx, nx = X0 + ax, ny = Y0 + bx;
-                double r = __builtin_amdgcn_rcp(Wq);
-                r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
-                r = __builtin_fma(__builtin_fma(-Wq, r, 1.0), r, r);
-                double fX = nx * r, fY = ny * r;
-                const bool sure = fabs(__builtin_amdgcn_fract(fX) - 0.5) > 1e-6 && fabs(__builtin_amdgcn_fract(fY) - 0.5) > 1e-6 &&
-                                  fabs(fX) < 1e9 && fabs(fY) < 1e9;
-                if (!sure) {
-                    const double Wd = Wq != 0 ? 1. / Wq : 0;
-                    fX = fmax((double)INT_MIN, fmin((double)INT_MAX, nx * Wd));
-                    fY = fmax((double)INT_MIN, fmin((double)INT_MAX, ny * Wd));
-                }
-                const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
-                v[q] = 0;
-                if (py[q] >= 0 && X >= 0 && X < W && Y >= 0 && Y < H) v[q] = src[(size_t)Y * a.row_stride + X];
+                v[q] = warp_gather<false>(src, a.row_stride, W, H, m1 * y + m2, m4 * y + m5, m7 * y + m8, m0 * x, m3 * x, m6 * x, py[q] >= 0);
             }
 #pragma unroll
             for (int q = 0; q < GQ; q++) {
@@ -224,24 +240,52 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
                 }
             }
         }
-        __syncthreads();
-        // four bins per lane: the candidate's 512-byte histogram row is written as whole cache lines
-        uint32_t hsum[4] = {0, 0, 0, 0};
-        if (bytes) {
-            uint32_t even = 0, odd = 0;   // bins 4*lane, 4*lane+2 and 4*lane+1, 4*lane+3 as halfword pairs
+    }
+    __syncthreads();
+    // four bins per lane: the candidate's 512-byte histogram row is written as whole cache lines
+    uint32_t hsum[4] = {0, 0, 0, 0};
+    if (bytes) {
+        uint32_t even = 0, odd = 0;   // bins 4*lane, 4*lane+2 and 4*lane+1, 4*lane+3 as halfword pairs
 #pragma unroll
-            for (int c = 0; c < HCOPIES; c++) {
-                const uint32_t w = hist[c * HPITCH + lane];
-                even += w & 0x00FF00FFu, odd += (w >> 8) & 0x00FF00FFu;
-            }
-            hsum[0] = even & 0xFFFFu, hsum[2] = even >> 16, hsum[1] = odd & 0xFFFFu, hsum[3] = odd >> 16;
-        } else {
-#pragma unroll
-            for (int c = 0; c < HWCOPIES; c++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) hsum[q] += hist[c * HWPITCH + 4 * lane + q];
+        for (int c = 0; c < HCOPIES; c++) {
+            const uint32_t w = hist[c * HPITCH + lane];
+            even += w & 0x00FF00FFu, odd += (w >> 8) & 0x00FF00FFu;
         }
-        ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2(hsum[0] | (hsum[1] << 16), hsum[2] | (hsum[3] << 16));
+        hsum[0] = even & 0xFFFFu, hsum[2] = even >> 16, hsum[1] = odd & 0xFFFFu, hsum[3] = odd >> 16;
+    } else {
+#pragma unroll
+        for (int c = 0; c < HWCOPIES; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) hsum[q] += hist[c * HWPITCH + 4 * lane + q];
+    }
+    ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2(hsum[0] | (hsum[1] << 16), hsum[2] | (hsum[3] << 16));
+}
+
+__global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
+    latency_bound_priority();
+    __shared__ uint32_t hist[HCOPIES * HPITCH];
+    __shared__ double siM[9];
+    const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
+    const int lane = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs. The candidate list is ordered by frame, and the candidates of a marker (its border, the
+    // outline of its quiet zone) sample the same pixels: XCD_RUN consecutive list entries go to one XCD, so that its L2 serves the second
+    // candidate's lines instead of HBM.
+    const uint32_t nslots = ((n + 8 * XCD_RUN - 1) / (8 * XCD_RUN)) * (8 * XCD_RUN);
+    for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
+        uint32_t idx = b;
+        if (XCD_RUN > 1) {
+            const uint32_t xcd = b & 7u, r = b >> 3;
+            idx = ((r / XCD_RUN) * 8u + xcd) * XCD_RUN + (r % XCD_RUN);
+        }
+        if (idx >= n) continue;
+        __syncthreads();
+        for (int i = lane; i < HCOPIES * HPITCH; i += WAVE) hist[i] = 0;
+        if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
+        __syncthreads();
+        if (a.ws == 8 * GQ && a.row_stride * (size_t)a.height < ((size_t)1 << 32))
+            warp_hist_candidate<8 * GQ>(a, idx, hist, siM, lane);
+        else
+            warp_hist_candidate<0>(a, idx, hist, siM, lane);
     }
 }
 
