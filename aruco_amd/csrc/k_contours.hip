@@ -867,12 +867,42 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     DPP_FOLD("v_min_u32_dpp", v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-// argmax with first-maximum tie break: every lane brings its best (value, position), positions are unique;
-// a lane without an element brings position 0xFFFFFFFF (its value is ignored)
+// argmax with first-maximum tie break: every lane brings its best (value, position), positions are unique; a lane whose elements are all zero
+// (or that has none) brings (0, 0xFFFFFFFF), so a maximum of zero comes back with position 0xFFFFFFFF
 __device__ __forceinline__ void wave_argmax_first(uint32_t val, uint32_t idx, uint32_t* max_val, uint32_t* first_idx) {
-    const uint32_t mv = wave_max_u32(idx == 0xFFFFFFFFu ? 0u : val);
+    const uint32_t mv = wave_max_u32(val);
     *max_val = mv;
-    *first_idx = wave_min_u32((idx != 0xFFFFFFFFu && val == mv) ? idx : 0xFFFFFFFFu);
+    *first_idx = wave_min_u32(val == mv ? idx : 0xFFFFFFFFu);
+}
+
+// The "farthest point" scans of approxPolyDP over the cyclic index range first, first + 1, ... (len entries, first < count, len <= count) as two
+// linear runs (up to the end of the border, then from its beginning), so that no entry needs a wrap test; every lane keeps the first maximum of its
+// own entries (only a strictly greater value replaces it, its entries come in scan order), the key is the scan position. A point is one 32-bit word
+// x | y << 16: the difference to the anchor is one v_pk_sub_i16 and the squared distance / the cross product one v_dot2_i32_i16 (coordinates are
+// below 2^14, so differences fit 16 bits and the sums 31).
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
+template <bool CROSS>
+__device__ __forceinline__ uint32_t scan_value(uint32_t pt, uint32_t anchor, uint32_t w) {
+    const short2v d = as_s2(pt) - as_s2(anchor);
+    if (!CROSS) return (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+    const int cr = __builtin_amdgcn_sdot2(d, as_s2(w), 0, false);
+    return (uint32_t)max(cr, -cr);
+}
+template <bool CROSS>
+__device__ __forceinline__ void scan_cyclic(const uint32_t* P32, int count, int first, int len, int lane, uint32_t anchor, uint32_t w, uint32_t& bd, uint32_t& bk) {
+    bd = 0, bk = 0xFFFFFFFFu;
+    const int lenA = min(len, count - first);
+    const uint32_t* pa = P32 + first;
+    for (int k = lane; k < lenA; k += WAVE) {
+        const uint32_t v = scan_value<CROSS>(pa[k], anchor, w);
+        if (v > bd) bd = v, bk = (uint32_t)k;
+    }
+    const uint32_t* pb = P32 - lenA;
+    for (int k = lenA + lane; k < len; k += WAVE) {
+        const uint32_t v = scan_value<CROSS>(pb[k], anchor, w);
+        if (v > bd) bd = v, bk = (uint32_t)k;
+    }
 }
 
 #ifndef EMIT_LANES_N
@@ -919,40 +949,39 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
         // EMIT_LANES lanes at a time: the kernel's speed follows its occupancy (12 KB of LDS per wave = 12 waves per CU measured
         // 0.67 ms, 24 KB 1.08 ms), and the blocks of a half wave cost 4 KB instead of 8; the emission is a fifth of the kernel
         const int maxbx = (a.tnx - 4) * 8, maxby = (a.tny - 4) * 8;
+        uint32_t* P32 = (uint32_t*)P;
+        const uint32_t* rb = rows + lane - EMIT_LANES;
         for (int k0 = 0; k0 < ncp; k0 += EMIT_LANES) {
-            if (lane >= EMIT_LANES) continue;
             const int k = k0 + lane;
-            const bool live = k < ncp;
-            const uint32_t c = ckp[live ? k : 0];
-            uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
-            int s = (int)(c >> 28);
-            const int n0 = k * CK, n1 = live ? min(n0 + CK, count) : n0;
+            if (lane >= EMIT_LANES || k >= ncp) continue;
+            const uint32_t c = ckp[k];
+            const uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
+            const int n0 = k * CK, n1 = min(n0 + CK, count);
             TileBlock blk;
             if (TB_DIRECTED)
-                tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, s, rows, lane, blk);
+                tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, (int)(c >> 28), rows, lane, blk);
             else
                 tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+            uint32_t base1 = tb_base1(blk), lp = pos - base1, s1c = tb_s1c((int)(c >> 28));
 #pragma unroll
             for (int j = 0; j < CK; j++) {
                 if (j == CK / 2) {
-                    const int lx = (int)(pos & 0xFFFFu) - blk.bx, ly = (int)(pos >> 16) - blk.by;
-                    const bool near = (lx < 1 + CK / 2 && blk.bx > 0) || (lx > 30 - CK / 2 && blk.bx < maxbx) || (ly < 1 + CK / 2 && blk.by > 0) ||
+                    const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
+                    const bool near = (lxm < CK / 2 && blk.bx > 0) || (lxm > 29 - CK / 2 && blk.bx < maxbx) || (ly < 1 + CK / 2 && blk.by > 0) ||
                                       (ly > 30 - CK / 2 && blk.by < maxby);
                     if (near && n0 + j < n1) {
+                        const uint32_t at = lp + base1;
                         if (TB_DIRECTED)
-                            tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, s, rows, lane, blk);
+                            tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, at, tb_s_of(s1c), rows, lane, blk);
                         else
-                            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
+                            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, at, rows, lane, blk);
+                        base1 = tb_base1(blk), lp = at - base1;
                     }
                 }
-                if (n0 + j < n1) {
-                    const uint32_t m = tb_mask<EMIT_LANES>(rows, lane, blk, pos);
-                    const uint32_t sh = (uint32_t)(s + 1) & 7u;
-                    const uint32_t rot = ((m | (m << 8)) >> sh) & 0xFFu;
-                    const int d = (int)((sh + (uint32_t)__builtin_ctz(rot | 0x100u)) & 7u);
-                    P[n0 + j] = make_short2((short)(pos & 0xFFFFu), (short)(pos >> 16));
-                    pos += tb_dpos(d);
-                    s = (d + 4) & 7;
+                // the points in LDS have CK entries of slack: the last lane walks on along the (closed) border instead of testing every step
+                if (LDSP || n0 + j < n1) {
+                    P32[n0 + j] = lp + base1;
+                    tb_step<EMIT_LANES>(rb, lp, s1c);
                 }
             }
         }
@@ -967,21 +996,13 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
     eps *= eps;
     int pos = 0, rs_start = 0;
     bool le_eps = false;
+    const uint32_t* PW = (const uint32_t*)P;
     for (int it = 0; it < 3; it++) {
         pos = (pos + rs_start) % count;
-        const short2 sp = P[pos];
-        uint32_t bd = 0, bj = 0xFFFFFFFFu;
-        for (int j = 1 + lane; j < count; j += WAVE) {
-            int q = pos + j;
-            if (q >= count) q -= count;
-            short2 pt = P[q];
-            int dx = pt.x - sp.x, dy = pt.y - sp.y;
-            const uint32_t d2 = (uint32_t)(dx * dx + dy * dy);
-            if (d2 > bd || bj == 0xFFFFFFFFu) bd = d2, bj = (uint32_t)j;
-        }
-        uint32_t maxd, jmax;
-        wave_argmax_first(bd, bj, &maxd, &jmax);
-        if (maxd > 0) rs_start = (int)jmax;
+        uint32_t bd, bk, maxd, kmax;
+        scan_cyclic<false>(PW, count, pos + 1 == count ? 0 : pos + 1, count - 1, lane, PW[pos], 0u, bd, bk);   // j = 1 .. count-1 at scan position j - 1
+        wave_argmax_first(bd, bk, &maxd, &kmax);
+        if (maxd > 0) rs_start = (int)kmax + 1;
         le_eps = (double)maxd <= eps;
     }
     int top = 0, outn = 0;
@@ -1015,16 +1036,10 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
         int split = 0;
         if (len > 1) {
             const int dx = ep.x - sp.x, dy = ep.y - sp.y;
-            uint32_t bd = 0, bq = 0xFFFFFFFFu;
-            for (int q = lane; q < len - 1; q += WAVE) {
-                int idx = sl_start + 1 + q;
-                if (idx >= count) idx -= count;
-                short2 pt = P[idx];
-                int cr = (pt.y - sp.y) * dx - (pt.x - sp.x) * dy;
-                uint32_t ad = (uint32_t)(cr < 0 ? -cr : cr);
-                if (ad > bd || bq == 0xFFFFFFFFu) bd = ad, bq = (uint32_t)q;
-            }
-            uint32_t maxd_u, qmax;
+            // |(pt.y - sp.y) * dx - (pt.x - sp.x) * dy| = |(pt - sp) . (-dy, dx)|
+            const uint32_t w = ((uint32_t)(-dy) & 0xFFFFu) | ((uint32_t)dx << 16);
+            uint32_t bd, bq, maxd_u, qmax;
+            scan_cyclic<true>(PW, count, sl_start + 1 == count ? 0 : sl_start + 1, len - 1, lane, PW[sl_start], w, bd, bq);
             wave_argmax_first(bd, bq, &maxd_u, &qmax);
             double maxd = (double)maxd_u;
             int q = qmax == 0xFFFFFFFFu ? 0 : (int)qmax;
@@ -1118,7 +1133,7 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
 
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     latency_bound_priority();
-    __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
+    __shared__ __align__(16) short2 Plds[QP_LDS + CK];   // contour points (+ the slack the last emitting lane may write)
     __shared__ uint32_t rows[TB_ROWS * EMIT_LANES];  // one 32x32-pixel block per emitting lane
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
