@@ -37,6 +37,9 @@ Tuning read_tuning() {
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
+#ifdef ARUCOHIP_STAGE_EXPERIMENT
+    t.stop_after = geti("ARUCOHIP_STOP_AFTER", 99);   // truncates the pipeline: results are meaningless, only the step time is
+#endif
     t.thres_lazy = geti("ARUCOHIP_THRES_BYTES", 0) == 0;
     if (const char* e = getenv("ARUCOHIP_GENS")) {
         for (const char* q = e; *q && t.ngens < 32;) {
@@ -802,39 +805,41 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b);
     } else {
-        launch_start_candidates(s, g, nframes * dp.nthr, b, dp.min_contour);
+        const int stop = b.tune.stop_after;   // 99 outside the stage-cost experiment
+        if (stop > 1) launch_start_candidates(s, g, nframes * dp.nthr, b, dp.min_contour);
         MARK(K_WALKERS);
         // walkers; their late generations run on the side stream under the first quad pass (the contour_quad mark sits at the fork)
         WalkFork fk{b.tune.walk_fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};
-        const bool forked = launch_walkers(s, fk, g, nframes * dp.nthr, dp, b);
+        const bool forked = stop > 2 ? launch_walkers(s, fk, g, nframes * dp.nthr, dp, b) : false;
         MARK(K_CONTOUR_QUADS);
-        launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
+        if (stop > 4) launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
         if (forked) {
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
-            launch_contour_quads(s, g, nframes, dp, b, 2);
+            if (stop > 4) launch_contour_quads(s, g, nframes, dp, b, 2);
         }
     }
+    const int stop = b.tune.stop_after;
     MARK(K_FRAME_CANDS);
-    launch_frame_candidates(s, g, nframes, dp, b);
+    if (stop > 5) launch_frame_candidates(s, g, nframes, dp, b);
     MARK(K_DECODE);
     // built-in 5x5 decoder: the cell votes and the Hamming decode of a candidate are the head of its refinement wave (one dispatch less)
     const bool fused_cells = dp.decoder == ARUCOHIP_DECODER_FIDUCIAL_5X5;
-    launch_decode(s, gray_dev, g, nframes, dp, b, fused_cells);
+    if (stop > 6) launch_decode(s, gray_dev, g, nframes, dp, b, fused_cells);
     if (dp.decoder == ARUCOHIP_DECODER_USER) {
         const int rc_ = user_decode_stage(h, dp);
         if (rc_) return rc_;
     }
     MARK(K_REFINE_LINES);
-    launch_refine_lines(s, g, nframes, dp, cam, b, fused_cells);
+    if (stop > 7) launch_refine_lines(s, g, nframes, dp, cam, b, fused_cells);
     MARK(K_REFINE_PIXELS);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX) {
         if (dp.locked) launch_locked_corners(s, gray_dev, g, nframes, dp, b);   // markerdetector.cpp:398-399
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
     }
     MARK(K_FINALIZE);
-    launch_finalize(s, g, nframes, dp, cam, b);
+    if (stop > 8) launch_finalize(s, g, nframes, dp, cam, b);
     MARK(K_POSE);
-    if (cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
+    if (stop > 8 && cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
     MARK(K_COUNT);
 #undef MARK
     if (tm) h->tsets++;

@@ -129,6 +129,8 @@ struct Tuning {
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
+    int stop_after = 99;       // stage-cost experiment (tools/stage_cost.sh; only a library built with -DARUCOHIP_STAGE_EXPERIMENT reads ARUCOHIP_STOP_AFTER):
+                               // 1 threshold, 2 start candidates, 3 first walker pass, 4 generations, 5 contour_quad, 6 frame_candidates, 7 warp + Otsu, 8 LINES
     int threshold_eo = 1;      // ARUCOHIP_THRESHOLD_EO: its round-3 form for 7x7 blocks (unpacked row ring, folded constants); 0 = the round-2 kernel
 };
 Tuning read_tuning();          // capi.hip

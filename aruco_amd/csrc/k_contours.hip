@@ -530,55 +530,77 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
         blk = *preloaded;   // the caller's block is centred on pos already
     else
         tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
-    bool walking = live;
-    int res = WR_LIMIT;
+    bool walking = live, was_bad = false, was_closed = false;   // the verdict is read off the two sticky flags after the loop
     const int maxbx = (tnx - 4) * 8, maxby = (tny - 4) * 8;
+    // Inside the loop the walk lives in block coordinates (bits_tiles.h: lp, s1c); everything a step compares against is brought into them when the
+    // block changes (differences of packed positions are exact modulo 2^32, so equality and the signed distance to the trigger survive).
+    uint32_t base1 = tb_base1(blk), lp = pos - base1, s1c = tb_s1c(s);
+    uint32_t p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
+    const uint32_t* rb = rows + lane - LANES;
     while (__any(walking)) {
         {
             // a side that is clamped to the image needs no margin: the border cannot leave the image
-            const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
-            const int lx = x - blk.bx, ly = y - blk.by;
-            const bool near = (lx < 1 + CHUNK && blk.bx > 0) || (lx > 30 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
+            const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
+            const bool near = (lxm < CHUNK && blk.bx > 0) || (lxm > 29 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
                               (ly > 30 - CHUNK && blk.by < maxby);
             // A closed 8-connected border that reaches Chebyshev distance d from its start has at least 2 d points (every step moves
             // at most one pixel in that metric, and the border returns): at 2 d >= nmax the size filter's verdict is known and the
             // walk ends here instead of after nmax steps.
             {
-                const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
-                if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, res = WR_BAD;
+                const uint32_t at = lp + base1;
+                const int ax = abs((int)(at & 0xFFFFu) - (int)(pos0 & 0xFFFFu)), ay = abs((int)(at >> 16) - (int)(pos0 >> 16));
+                if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, was_bad = true;
             }
             if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) {
+                const uint32_t at = lp + base1;
                 if (TB_DIRECTED)
-                    tb_load_dir<LANES>(tiles, tnx, tny, pos, s, rows, lane, blk);
+                    tb_load_dir<LANES>(tiles, tnx, tny, at, tb_s_of(s1c), rows, lane, blk);
                 else
-                    tb_load<LANES>(tiles, tnx, tny, pos, rows, lane, blk);
+                    tb_load<LANES>(tiles, tnx, tny, at, rows, lane, blk);
+                base1 = tb_base1(blk), lp = at - base1;
+                p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
             }
         }
-        const uint32_t* rb = rows + lane - (blk.by + 1) * LANES;   // row y of the image sits at rb[y * LANES]
-        const int xo = -blk.bx - 1;
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
             if (walking) {
-                if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(pos, s);
-                const uint32_t* r = rb + (pos >> 16) * LANES;
-                const int sh = (int)(pos & 0xFFFFu) + xo;
-                const uint32_t up = (r[0] >> sh) & 7u, mid = (r[LANES] >> sh) & 7u, dn = (r[2 * LANES] >> sh) & 7u;
+                if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(lp + base1, tb_s_of(s1c));
+                const uint32_t* r = rb + (lp >> 16) * LANES;
+                const uint32_t up = __builtin_amdgcn_ubfe(r[0], lp, 3u), mid = __builtin_amdgcn_ubfe(r[LANES], lp, 3u), dn = __builtin_amdgcn_ubfe(r[2 * LANES], lp, 3u);
                 // ring E,NE,N,NW,W,SW,S,SE: the reversed `up` lands on bits 1..3
                 const uint32_t m = (__builtin_bitreverse32(up) >> 28) | (mid >> 2) | ((mid & 1u) << 4) | (dn << 5);
+                // walk_step<HOLE, false> on the selector-shaped direction state: the search starts at rotation (s + 1) & 7 = the state's low bits
+                const uint32_t rot = (m | (m << 8)) >> (s1c & 31u);
+                const uint32_t k = (uint32_t)__builtin_ctz(rot);   // a pixel of a border that is being followed has a neighbour
                 bool bad;
-                const int d = walk_step<HOLE, false>(m, s, pos, tkey, pos0, &bad);
-                ++n;
-                const uint32_t npos = pos + tb_dpos(d);
-                const bool closed = npos == pos0 && pos == pos1;
-                const bool stay = bad | closed;
-                if (stay | (n >= lim)) {
-                    walking = false;
-                    res = bad ? WR_BAD : closed ? WR_CLOSED : WR_LIMIT;
+                if (HOLE) {
+                    // examined 4-neighbours z = pos + off precede tkey iff delta = pos - tkey < -off; N < W < E < S in raster order
+                    const int delta = (int)(lp - tkb);
+                    uint32_t hit = 0;   // an integer, not a flag, crosses the branch: a flag would be turned into one and back
+                    if (delta < 65536) {                       // only near or above the trigger row
+                        uint32_t ex;                           // ((1 << k) - 1) << sh: directions examined and found empty
+                        asm("v_bfm_b32 %0, %1, %2" : "=v"(ex) : "v"(k), "v"(s1c));   // uses the low 5 bits of both, and the state's are (s + 1) & 7
+                        const uint32_t cm = 4u | (delta < 1 ? 16u : 0u) | (delta < -1 ? 1u : 0u) | (delta < -65536 ? 64u : 0u);
+                        hit = (ex | (ex >> 8)) & cm;
+                    }
+                    asm volatile("" : "+v"(hit));   // keeps the compare below the branch, where its result is a lane mask
+                    bad = hit != 0;
+                } else {
+                    bad = lp + base1 < pos0;
                 }
-                if (!stay) pos = npos, s = (d + 4) & 7;
+                const uint32_t ns1c = ((s1c + k + 5u) & 7u) | TB_S1C;   // d = (sh + k) & 7, back direction (d + 4) & 7, next rotation (d + 5) & 7
+                const uint32_t nb = __builtin_amdgcn_perm(0x01021222u, 0x21201000u, ns1c);
+                const uint32_t nlp = lp + ((nb | (nb << 12)) & 0x000F000Fu) - 65537u;
+                ++n;
+                const bool closed = nlp == p0b && lp == p1b;
+                was_bad |= bad, was_closed |= closed;
+                walking = !(bad | closed | (n >= lim));
+                lp = nlp, s1c = ns1c;   // also when the walk has ended: position and direction only matter to a walk that goes on (WR_LIMIT)
             }
         }
     }
+    const int res = was_bad ? WR_BAD : was_closed ? WR_CLOSED : WR_LIMIT;
+    pos = lp + base1, s = tb_s_of(s1c);
     return res;
 }
 
@@ -820,7 +842,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     int done = a.leash;
     bool forked = false;
     hipStream_t cur = s;
-    for (int g = 1; g <= GEN_MAX && done < p.max_contour; g++) {
+    for (int g = 1; g <= GEN_MAX && done < p.max_contour && b.tune.stop_after > 3; g++) {   // stop_after: stage-cost experiment only (internal.h)
         if (g == kForkAfter + 1 && fk.side) {
             hipLaunchKernelGGL(snapshot_kernel, dim3((nplanes + 255) / 256), dim3(256), 0, s, b.trig_cnt, nplanes);
             (void)hipEventRecord(fk.forked, s);
