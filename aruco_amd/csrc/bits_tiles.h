@@ -63,15 +63,28 @@ struct TileBlock {
     int bx, by;   // pixel origin of the block (multiples of 8)
 };
 
-// load the block whose top-left tile is (tx0, ty0); the caller keeps it inside the tile array (0 <= tx0 <= tnx-4, same in y)
-template <int LANES>
-__device__ __forceinline__ void tb_load_at(const uint64_t* __restrict__ tiles, int tnx, int tx0, int ty0, uint32_t* rows, int lane, TileBlock& b) {
+// A block in two halves: the 16 tile loads (4 x 4 tiles of 8 bytes) into registers, and the transposition into the lane's 32 row words in LDS. A follower
+// issues the loads of the block it will need NEXT while it still walks in the current one and transposes them when it gets there (k_contours.hip,
+// walk_run): the load latency (1-2 us under load, once per 4-8 steps of a wave) was what the walkers spent their time on.
+struct TileRegs {
+    uint64_t t[16];
+};
+// the caller keeps the block inside the tile array (0 <= tx0 <= tnx-4, same in y)
+__device__ __forceinline__ void tb_fetch_at(const uint64_t* __restrict__ tiles, int tnx, int tx0, int ty0, TileRegs& T, TileBlock& b) {
     b.bx = tx0 * 8, b.by = ty0 * 8;
     const uint64_t* p = tiles + (size_t)ty0 * tnx + tx0;
 #pragma unroll
     for (int tr = 0; tr < 4; tr++) {
-        const uint64_t t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) T.t[tr * 4 + k] = p[k];
         p += tnx;
+    }
+}
+template <int LANES>
+__device__ __forceinline__ void tb_store(const TileRegs& T, uint32_t* rows, int lane) {
+#pragma unroll
+    for (int tr = 0; tr < 4; tr++) {
+        const uint64_t t0 = T.t[tr * 4], t1 = T.t[tr * 4 + 1], t2 = T.t[tr * 4 + 2], t3 = T.t[tr * 4 + 3];
 #pragma unroll
         for (int h = 0; h < 2; h++) {            // low / high half of the tiles: rows 4h .. 4h+3 of this tile row
             const uint32_t a0 = (uint32_t)(t0 >> (32 * h)), a1 = (uint32_t)(t1 >> (32 * h));
@@ -88,6 +101,12 @@ __device__ __forceinline__ void tb_load_at(const uint64_t* __restrict__ tiles, i
         }
     }
 }
+template <int LANES>
+__device__ __forceinline__ void tb_load_at(const uint64_t* __restrict__ tiles, int tnx, int tx0, int ty0, uint32_t* rows, int lane, TileBlock& b) {
+    TileRegs T;
+    tb_fetch_at(tiles, tnx, tx0, ty0, T, b);
+    tb_store<LANES>(T, rows, lane);
+}
 
 // block centred on pos: after the load pos is at least 11 pixels from every edge of the block (image borders aside)
 template <int LANES>
@@ -97,17 +116,22 @@ __device__ __forceinline__ void tb_load(const uint64_t* __restrict__ tiles, int 
     tb_load_at<LANES>(tiles, tnx, tx0, ty0, rows, lane, b);
 }
 
-// The same for a walk in progress: s = direction that points at the PREVIOUS border pixel, so the walk is heading the other way. The block
-// is placed with the pixel 9..16 pixels from the edge it comes from (what the followers' edge tests need: 8 steps of room in every
-// direction) and 15..22 pixels from the edge it is heading for, instead of 12..19 from both: a border that keeps its direction travels
-// 6..13 pixels before the next re-centring instead of 3..10. Purely a placement: which block a lane holds never changes what it reads.
-template <int LANES>
-__device__ __forceinline__ void tb_load_dir(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, int s, uint32_t* rows, int lane, TileBlock& b) {
-    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
+// The same for a walk in progress: s = direction that points at the PREVIOUS border pixel, so the walk is heading the other way. M = steps the
+// follower takes between two looks at the block edge (it needs M steps of room in every direction). The block is placed with the pixel
+// M+1 .. M+8 pixels from the edge it comes from and 23-M .. 30-M pixels from the edge it is heading for (M = 8: 9..16 and 15..22, instead of 12..19
+// from both): a border that keeps its direction travels 6..13 pixels before the next re-centring instead of 3..10 (M = 4: 14..21).
+// Purely a placement: which block a lane holds never changes what it reads.
+template <int M>
+__device__ __forceinline__ void tb_place_dir(int tnx, int tny, int x, int y, int s, int* tx0, int* ty0) {
     // heading = -step(s): dx of direction s is +1 for E, NE, SE (0, 1, 7), -1 for NW, W, SW (3, 4, 5); dy is -1 for NE, N, NW (1, 2, 3), +1 for SW, S, SE
     const int sdx = (0x83u >> s) & 1 ? 1 : ((0x38u >> s) & 1 ? -1 : 0), sdy = (0x0Eu >> s) & 1 ? -1 : ((0xE0u >> s) & 1 ? 1 : 0);
-    const int offx = sdx > 0 ? 15 : (sdx < 0 ? 9 : 12), offy = sdy > 0 ? 15 : (sdy < 0 ? 9 : 12);   // previous pixel to the east: heading west: far from the west edge
-    const int tx0 = min(max((x - offx) >> 3, 0), tnx - 4), ty0 = min(max((y - offy) >> 3, 0), tny - 4);
+    const int offx = sdx > 0 ? 23 - M : (sdx < 0 ? M + 1 : 12), offy = sdy > 0 ? 23 - M : (sdy < 0 ? M + 1 : 12);   // previous pixel to the east: heading west: far from the west edge
+    *tx0 = min(max((x - offx) >> 3, 0), tnx - 4), *ty0 = min(max((y - offy) >> 3, 0), tny - 4);
+}
+template <int LANES, int M = 8>
+__device__ __forceinline__ void tb_load_dir(const uint64_t* __restrict__ tiles, int tnx, int tny, uint32_t pos, int s, uint32_t* rows, int lane, TileBlock& b) {
+    int tx0, ty0;
+    tb_place_dir<M>(tnx, tny, (int)(pos & 0xFFFFu), (int)(pos >> 16), s, &tx0, &ty0);
     tb_load_at<LANES>(tiles, tnx, tx0, ty0, rows, lane, b);
 }
 

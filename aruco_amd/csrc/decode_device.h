@@ -10,13 +10,16 @@
 
 namespace ah {
 
-// element k of this lane's matrix at k * 64 + lane: the 64 lanes of a wave never collide on a bank
+// The 8x8 systems of HOMOGRAPHY_GROUP lanes at a time live in LDS, element-major: element k of a lane's matrix at k * GROUP + (lane % GROUP), so the lanes
+// of a group never collide on a bank. A wave solves its 64 candidates group after group (round 3: all 64 at once took 37 KB, and with the batches in
+// flight a workgroup that wants a quarter of a CU's LDS waits for it: 0.61 ms in the stream against 0.07 alone).
+constexpr int HOMOGRAPHY_GROUP = 16;
 struct LaneMat {
     double* base;
     int lane;
-    __device__ __forceinline__ double& operator[](int k) const { return base[k * 64 + lane]; }
+    __device__ __forceinline__ double& operator[](int k) const { return base[k * HOMOGRAPHY_GROUP + (lane & (HOMOGRAPHY_GROUP - 1))]; }
 };
-constexpr int HOMOGRAPHY_LDS_DOUBLES = 64 * 64 + 8 * 64;   // A (8 x 8) and b (8) of 64 lanes
+constexpr int HOMOGRAPHY_LDS_DOUBLES = 64 * HOMOGRAPHY_GROUP + 8 * HOMOGRAPHY_GROUP;   // A (8 x 8) and b (8) of a group
 
 // qx / qy: the candidate's integer corners; iM: 9 doubles. Gaussian elimination with partial pivoting, same operation order as the CPU
 // restatement of cv::getPerspectiveTransform + the inversion cv::warpPerspective starts with.

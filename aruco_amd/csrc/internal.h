@@ -195,6 +195,11 @@ struct Buffers {
 #define LBP_PRIO 3
 #endif
 __device__ __forceinline__ void latency_bound_priority() { if (LBP_PRIO > 0) __builtin_amdgcn_s_setprio(LBP_PRIO); }
+// The kernels with many busy waves (contour_quad, warp_hist, start candidates): between the streaming pass and the sparse chains
+#ifndef LBP_PRIO_HEAVY
+#define LBP_PRIO_HEAVY LBP_PRIO
+#endif
+__device__ __forceinline__ void throughput_bound_priority() { if (LBP_PRIO_HEAVY > 0) __builtin_amdgcn_s_setprio(LBP_PRIO_HEAVY); }
 
 // ---- kernel launchers (host side, defined in the .hip files)
 void launch_bgr2gray(hipStream_t s, const uint8_t* bgr, size_t row_stride, size_t frame_stride, int width, int height, int nframes, uint8_t* gray);

@@ -197,6 +197,7 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
     // flight. A gather costs about as much as the number of distinct 128-byte lines it touches: a patch ROW of a rotated
     // marker crosses 56 image rows, an 8x8 block of the patch covers about 21 x 21 source pixels whatever the rotation.
     const int bxl = lane & 7, byl = lane >> 3;
+    uint32_t psum = 0;   // this lane's share of the sum of the patch's pixels = sum of i * hist[i]: the numerator of Otsu's mean, exact in integers
     if (WS == 8 * GQ) {
         double ax[GQ], bx[GQ], cx[GQ];
 #pragma unroll
@@ -214,6 +215,7 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
 #pragma unroll
             for (int q = 0; q < GQ; q++) {
                 prow[BY * 8 * WS + q * 8] = v[q];
+                psum += v[q];
                 atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
             }
         }
@@ -233,6 +235,7 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
             for (int q = 0; q < GQ; q++) {
                 if (py[q] >= 0) {
                     patch[py[q] * ws + px[q]] = v[q];
+                    psum += v[q];
                     if (bytes)
                         atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
                     else
@@ -259,10 +262,14 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
             for (int q = 0; q < 4; q++) hsum[q] += hist[c * HWPITCH + 4 * lane + q];
     }
     ((uint2*)(a.hist + (size_t)idx * 256))[lane] = make_uint2(hsum[0] | (hsum[1] << 16), hsum[2] | (hsum[3] << 16));
+    // the pixel sum travels in the candidate's threshold slot: otsu_kernel reads it there and puts the threshold in its place
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) psum += (uint32_t)__shfl_xor((int)psum, o, 64);
+    if (lane == 0) a.othr[idx] = (int32_t)psum;
 }
 
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
-    latency_bound_priority();
+    throughput_bound_priority();
     __shared__ uint32_t hist[HCOPIES * HPITCH];
     __shared__ double siM[9];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
@@ -289,63 +296,69 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     }
 }
 
-// 5c: one lane per candidate — getThreshVal_Otsu_8u, strictly sequential in double like the reference. The 64 histograms
-// of a workgroup are first brought into LDS with coalesced reads (bin-major, so that the lanes' sweeps read neighbouring
-// halfwords); the two 256-step sweeps then never wait for HBM.
+// 5c: one lane per candidate — getThreshVal_Otsu_8u, strictly sequential in double like the reference. Its first sweep (mu = sum of i * h[i],
+// all integers, exact in double in any order) is the sum of the patch's pixels, which warp_hist_kernel left in the candidate's threshold slot, so
+// only the sigma sweep remains. The histograms of the workgroup's 64 candidates are brought into LDS a quarter (64 bins) at a time with coalesced
+// reads (bin-major, so that the lanes' sweeps read neighbouring halfwords): 8.4 KB instead of the 34 KB of all bins at once. Round 3: with the batches
+// in flight a workgroup that needs a fifth of a CU's LDS waits for it, this kernel ran 0.41 ms in the stream against 0.06 alone (overlap trace).
 constexpr int OTSU_PITCH = 66;   // halfwords per bin row: 64 candidates + padding against bank conflicts
+constexpr int OTSU_BINS = 64;    // bins staged at a time
 __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     latency_bound_priority();
-    __shared__ uint16_t sh[256 * OTSU_PITCH];
+    __shared__ uint16_t sh[OTSU_BINS * OTSU_PITCH];
     const uint32_t n = min(a.counters[CNT_NCAND], a.cap_flat);
     const uint32_t base = blockIdx.x * 64;
     if (base >= n) return;
     const int lane = threadIdx.x;
     const int cnt = (int)min(64u, n - base);
-    // 8 histogram rows in flight per step (two dwords per lane and row)
-    for (int c0 = 0; c0 < cnt; c0 += 8) {
-        uint32_t v[8][2];
+    const uint32_t idx = base + min(lane, cnt - 1);
+    const int npx = a.ws * a.ws;
+    const double scale = 1. / npx;
+    const double mu = (double)(uint32_t)a.othr[idx] * scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    constexpr int DW = OTSU_BINS / 2;          // dwords of a candidate's row per stage
+    constexpr int CPL = 64 / DW;               // candidates a load instruction covers
+    for (int stage = 0; stage < 256 / OTSU_BINS; stage++) {
+        __syncthreads();
+        // 8 loads in flight per step: lane -> candidate c0 + CPL * j + lane / DW, dword stage * DW + lane % DW of its row
+        for (int c0 = 0; c0 < cnt; c0 += 8 * CPL) {
+            uint32_t v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t* row = (const uint32_t*)(a.hist + (size_t)(base + min(c0 + j, cnt - 1)) * 256);
-            v[j][0] = row[lane], v[j][1] = row[lane + 64];
+            for (int j = 0; j < 8; j++) {
+                const int c = min(c0 + CPL * j + lane / DW, cnt - 1);
+                v[j] = ((const uint32_t*)(a.hist + (size_t)(base + c) * 256))[stage * DW + (lane % DW)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = c0 + CPL * j + lane / DW;
+                if (c < cnt) {
+                    const int k = 2 * (lane % DW);
+                    sh[k * OTSU_PITCH + c] = (uint16_t)(v[j] & 0xFFFFu);
+                    sh[(k + 1) * OTSU_PITCH + c] = (uint16_t)(v[j] >> 16);
+                }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int c = c0 + j;
-            if (c < cnt) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int k = lane + 64 * q;
-                    sh[(2 * k) * OTSU_PITCH + c] = (uint16_t)(v[j][q] & 0xFFFFu);
-                    sh[(2 * k + 1) * OTSU_PITCH + c] = (uint16_t)(v[j][q] >> 16);
+        __syncthreads();
+        if (lane < cnt) {
+            const uint16_t* h = sh + lane;
+            for (int ii = 0; ii < OTSU_BINS; ii++) {
+                const int i = stage * OTSU_BINS + ii;
+                double p_i = h[ii * OTSU_PITCH] * scale;
+                mu1 *= q1;
+                q1 += p_i;
+                double q2 = 1. - q1;
+                if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+                mu1 = (mu1 + i * p_i) / q1;
+                double mu2 = (mu - q1 * mu1) / q2;
+                double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                if (sigma > max_sigma) {
+                    max_sigma = sigma;
+                    max_val = i;
                 }
             }
         }
     }
-    __syncthreads();
-    if (lane >= cnt) return;
-    const uint32_t idx = base + lane;
-    const int npx = a.ws * a.ws;
-    const uint16_t* h = sh + lane;
-    double mu = 0, scale = 1. / npx;
-    for (int i = 0; i < 256; i++) mu += i * (double)h[i * OTSU_PITCH];
-    mu *= scale;
-    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-    for (int i = 0; i < 256; i++) {
-        double p_i = h[i * OTSU_PITCH] * scale;
-        mu1 *= q1;
-        q1 += p_i;
-        double q2 = 1. - q1;
-        if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
-        mu1 = (mu1 + i * p_i) / q1;
-        double mu2 = (mu - q1 * mu1) / q2;
-        double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-        if (sigma > max_sigma) {
-            max_sigma = sigma;
-            max_val = i;
-        }
-    }
-    a.othr[idx] = (int)max_val;
+    if (lane < cnt) a.othr[idx] = (int)max_val;
 }
 
 // 5d: one wavefront per candidate — 7x7 cell votes on the binarised patch and the 5x5 Hamming decode (decode_device.h). Since round 3 the
