@@ -515,19 +515,11 @@ __device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lan
 #define TB_DIRECTED 1   // re-centre a walk's block ahead of the walk instead of around it (bits_tiles.h: tb_load_dir)
 #endif
 #ifndef CHUNK_N
-#define CHUNK_N 8
+#define CHUNK_N 4
 #endif
-#ifndef WALK_PREFETCH
-#define WALK_PREFETCH 0
-#endif
-#ifndef PF_LEAD_N
-#define PF_LEAD_N 8
-#endif
-#ifndef PF_AHEAD_N
-#define PF_AHEAD_N 4
-#endif
-constexpr int PF_LEAD = PF_LEAD_N, PF_AHEAD = PF_AHEAD_N;
-constexpr int CHUNK = CHUNK_N;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length)
+constexpr int CHUNK = CHUNK_N;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length). Round 3: 4 instead of 8 -
+                                 // a lane needs 4 steps of room instead of 8, a directed block serves 14..21 pixels of travel instead of 6..13 and the generations
+                                 // fetch a third fewer tiles (0.615 -> 0.597 ms; the first pass, whose walks are short, pays 0.167 -> 0.199; stream +1.2 %)
 
 // Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
 // (WR_CLOSED) or n == lim (WR_LIMIT, state advanced so that the walk can be resumed). All lanes of the wave step together.
@@ -550,15 +542,10 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
     uint32_t base1 = tb_base1(blk), lp = pos - base1, s1c = tb_s1c(s);
     uint32_t p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
     const uint32_t* rb = rows + lane - LANES;
-    // the block after this one: its tiles are requested while the walk is still PF_LEAD steps or less from needing it (bits_tiles.h: TileRegs)
-    TileRegs nxt;
-    TileBlock nblk{0, 0};
-    bool pend = false;
     while (__any(walking)) {
-        bool sit = false;   // this lane waits for its tiles this chunk (WALK_PREFETCH)
         {
             // a side that is clamped to the image needs no margin: the border cannot leave the image
-            int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
+            const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
             const bool near = (lxm < CHUNK && blk.bx > 0) || (lxm > 29 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) ||
                               (ly > 30 - CHUNK && blk.by < maxby);
             // A closed 8-connected border that reaches Chebyshev distance d from its start has at least 2 d points (every step moves
@@ -570,45 +557,7 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
                 if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, was_bad = true;
             }
-            if (WALK_PREFETCH) {
-                // Split-phase re-centring: a lane never waits for its tiles in the iteration that asks for them. Near the edge with a block on its
-                // way that serves (the pixel has CHUNK steps of room in it; the walk may have turned since the request) the lane transposes it - the
-                // loads were issued at least CHUNK steps ago. Otherwise it asks for the block around its pixel and SITS THIS CHUNK OUT (the other lanes
-                // walk on; the wave as a whole no longer stalls once per chunk for the slowest load).
-                if (walking && near) {
-                    bool have = false;
-                    if (pend) {
-                        const int nx = x - nblk.bx - 1, ny = y - nblk.by;
-                        have = !((nx < CHUNK && nblk.bx > 0) || (nx > 29 - CHUNK && nblk.bx < maxbx) || (ny < 1 + CHUNK && nblk.by > 0) || (ny > 30 - CHUNK && nblk.by < maxby));
-                    }
-                    if (have) {
-                        tb_store<LANES>(nxt, rows, lane);
-                        blk = nblk, pend = false;
-                        base1 = tb_base1(blk), lp = at - base1;
-                        p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
-                        lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);
-                    } else {
-                        int tx0, ty0;
-                        tb_place_dir<CHUNK>(tnx, tny, x, y, tb_s_of(s1c), &tx0, &ty0);
-                        tb_fetch_at(tiles, tnx, tx0, ty0, nxt, nblk);
-                        pend = true, sit = true;
-                    }
-                }
-                // look-ahead: the walk is within PF_LEAD + CHUNK pixels of the edge it is heading for (it re-centres within PF_LEAD steps if it keeps
-                // going): the block is requested for the pixel PF_AHEAD steps on, with the room the follower needs behind it
-                if (PF_LEAD > 0) {
-                    const int s_now = tb_s_of(s1c);
-                    const int hx = (0x83u >> s_now) & 1 ? -1 : ((0x38u >> s_now) & 1 ? 1 : 0), hy = (0x0Eu >> s_now) & 1 ? 1 : ((0xE0u >> s_now) & 1 ? -1 : 0);
-                    const bool appr = (hx < 0 && lxm < CHUNK + PF_LEAD && blk.bx > 0) || (hx > 0 && lxm > 29 - CHUNK - PF_LEAD && blk.bx < maxbx) ||
-                                      (hy < 0 && ly < 1 + CHUNK + PF_LEAD && blk.by > 0) || (hy > 0 && ly > 30 - CHUNK - PF_LEAD && blk.by < maxby);
-                    if (walking && !pend && appr) {
-                        int tx0, ty0;
-                        tb_place_dir<CHUNK>(tnx, tny, x + PF_AHEAD * hx, y + PF_AHEAD * hy, s_now, &tx0, &ty0);
-                        tb_fetch_at(tiles, tnx, tx0, ty0, nxt, nblk);
-                        pend = true;
-                    }
-                }
-            } else if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) {
+            if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) {
                 if (TB_DIRECTED)
                     tb_load_dir<LANES, CHUNK>(tiles, tnx, tny, at, tb_s_of(s1c), rows, lane, blk);
                 else
@@ -619,7 +568,7 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
         }
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
-            if (walking && !sit) {
+            if (walking) {
                 if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(lp + base1, tb_s_of(s1c));
                 const uint32_t* r = rb + (lp >> 16) * LANES;
                 const uint32_t up = __builtin_amdgcn_ubfe(r[0], lp, 3u), mid = __builtin_amdgcn_ubfe(r[LANES], lp, 3u), dn = __builtin_amdgcn_ubfe(r[2 * LANES], lp, 3u);
@@ -837,10 +786,6 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
 __global__ __launch_bounds__(64) void walker_long_kernel(WalkArgs a) {
     latency_bound_priority();
     __shared__ uint32_t rows[TB_ROWS * 64];   // one 32x32-pixel block per lane
-#ifdef LDS_PAD_WL   // experiment: how much the stream loses when this kernel's waves hold more LDS (profiles/r03_kernel_experiments.txt)
-    __shared__ uint32_t pad[LDS_PAD_WL / 4];
-    ((volatile uint32_t*)pad)[threadIdx.x] = 0;
-#endif
     if ((int)blockIdx.x < a.gen_blocks)
         walk_generation<false>(a, blockIdx.x, rows);
     else
@@ -1220,10 +1165,6 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
     __shared__ int s_outn;
-#ifdef LDS_PAD_CQ
-    __shared__ uint32_t pad[LDS_PAD_CQ / 4];
-    ((volatile uint32_t*)pad)[threadIdx.x] = 0;
-#endif
     // 1-D grid dealt round-robin over the 8 XCDs: all workgroups of a plane land on one XCD, whose L2 then serves the plane's tiles,
     // descriptors and checkpoints to all of them (same unpacking as walker_kernel)
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
