@@ -515,11 +515,12 @@ __device__ __forceinline__ uint32_t tb_mask_mirror(const uint32_t* rows, int lan
 #define TB_DIRECTED 1   // re-centre a walk's block ahead of the walk instead of around it (bits_tiles.h: tb_load_dir)
 #endif
 #ifndef CHUNK_N
-#define CHUNK_N 4
+#define CHUNK_N 8
 #endif
-constexpr int CHUNK = CHUNK_N;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length). Round 3: 4 instead of 8 -
-                                 // a lane needs 4 steps of room instead of 8, a directed block serves 14..21 pixels of travel instead of 6..13 and the generations
-                                 // fetch a third fewer tiles (0.615 -> 0.597 ms; the first pass, whose walks are short, pays 0.167 -> 0.199; stream +1.2 %)
+constexpr int CHUNK = CHUNK_N;   // steps taken between two looks at the block edge (divides CK, LEASH and every generation length). Round 3 measured 4: a lane then
+                                 // needs 4 steps of room, a directed block serves 14..21 pixels of travel instead of 6..13 and the generations fetch a fifth fewer
+                                 // bytes - +1.2 % on the bench's stream, -17 % on the cluttered one (148k against 178k frames/s: many short, wiggly borders pay
+                                 // the edge tests twice as often). 8 stays.
 
 // Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
 // (WR_CLOSED) or n == lim (WR_LIMIT, state advanced so that the walk can be resumed). All lanes of the wave step together.
