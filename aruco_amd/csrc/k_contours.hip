@@ -993,11 +993,15 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
         const int ncp = (count + CK - 1) / CK;
         const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
         // Every lane resumes the walk at one checkpoint and records CK = 16 points. The neighbourhoods come from the lane's own
-        // 32x32-pixel block in LDS (one load of eight 16-byte pieces instead of six dependent tile reads per step): a block
-        // centred on the checkpoint leaves at least 11 steps of room, so it is re-centred once, after 8 steps, where needed.
+        // 32x32-pixel block in LDS (one load of eight 16-byte pieces instead of six dependent tile reads per step). ONE block serves the
+        // whole stretch because both of its ends are known - this checkpoint and the next one (the border's start for the last stretch): a path
+        // of L steps from A to B cannot leave their bounding box by more than (L - |dx|) / 2 columns or (L - |dy|) / 2 rows (a pixel further
+        // out would need more than L steps to be reached from A and left towards B), so with the ring of neighbours the stretch spans at most
+        // 19 pixels each way and a tile-aligned block of 32 that holds it always exists. (Until round 3 the block was placed by the heading at
+        // the checkpoint and re-centred after 8 steps where needed - almost always for some lane: a second load per round, a fifth of the
+        // kernel's vector instructions.)
         // EMIT_LANES lanes at a time: the kernel's speed follows its occupancy (12 KB of LDS per wave = 12 waves per CU measured
-        // 0.67 ms, 24 KB 1.08 ms), and the blocks of a half wave cost 4 KB instead of 8; the emission is a fifth of the kernel
-        const int maxbx = (a.tnx - 4) * 8, maxby = (a.tny - 4) * 8;
+        // 0.67 ms, 24 KB 1.08 ms), and the blocks of a half wave cost 4 KB instead of 8
         uint32_t* P32 = (uint32_t*)P;
         const uint32_t* rb = rows + lane - EMIT_LANES;
         for (int k0 = 0; k0 < ncp; k0 += EMIT_LANES) {
@@ -1006,29 +1010,23 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
             const uint32_t c = ckp[k];
             const uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
             const int n0 = k * CK, n1 = min(n0 + CK, count);
+            int bx, by;   // where the stretch ends
+            if (k + 1 < ncp) {
+                const uint32_t cn = ckp[k + 1];
+                bx = (int)(cn & 0x3FFFu), by = (int)((cn >> 14) & 0x3FFFu);
+            } else {
+                bx = cd.x0, by = cd.y0;
+            }
+            const int ax = (int)(pos & 0xFFFFu), ay = (int)(pos >> 16), L = n1 - n0;
+            const int ex = (L - abs(bx - ax)) >> 1, ey = (L - abs(by - ay)) >> 1;
+            const int tx0 = min(max((min(ax, bx) - ex - 1) >> 3, 0), a.tnx - 4), ty0 = min(max((min(ay, by) - ey - 1) >> 3, 0), a.tny - 4);
             TileBlock blk;
-            if (TB_DIRECTED)
-                tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, pos, (int)(c >> 28), rows, lane, blk);
-            else
-                tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, pos, rows, lane, blk);
-            uint32_t base1 = tb_base1(blk), lp = pos - base1, s1c = tb_s1c((int)(c >> 28));
+            tb_load_at<EMIT_LANES>(tiles, a.tnx, tx0, ty0, rows, lane, blk);
+            const uint32_t base1 = tb_base1(blk);
+            uint32_t lp = pos - base1, s1c = tb_s1c((int)(c >> 28));
 #pragma unroll
             for (int j = 0; j < CK; j++) {
-                if (j == CK / 2) {
-                    const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
-                    const bool near = (lxm < CK / 2 && blk.bx > 0) || (lxm > 29 - CK / 2 && blk.bx < maxbx) || (ly < 1 + CK / 2 && blk.by > 0) ||
-                                      (ly > 30 - CK / 2 && blk.by < maxby);
-                    if (near && n0 + j < n1) {
-                        const uint32_t at = lp + base1;
-                        if (TB_DIRECTED)
-                            tb_load_dir<EMIT_LANES>(tiles, a.tnx, a.tny, at, tb_s_of(s1c), rows, lane, blk);
-                        else
-                            tb_load<EMIT_LANES>(tiles, a.tnx, a.tny, at, rows, lane, blk);
-                        base1 = tb_base1(blk), lp = at - base1;
-                    }
-                }
-                // the points in LDS have CK entries of slack: the last lane walks on along the (closed) border instead of testing every step
-                if (LDSP || n0 + j < n1) {
+                if (n0 + j < n1) {
                     P32[n0 + j] = lp + base1;
                     tb_step<EMIT_LANES>(rb, lp, s1c);
                 }
@@ -1182,7 +1180,7 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
 
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     throughput_bound_priority();
-    __shared__ __align__(16) short2 Plds[QP_LDS + CK];   // contour points (+ the slack the last emitting lane may write)
+    __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
     __shared__ uint32_t rows[TB_ROWS * EMIT_LANES];  // one 32x32-pixel block per emitting lane
     __shared__ int s_stack[16][2];
     __shared__ short2 s_out[12];
