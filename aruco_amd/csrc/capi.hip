@@ -754,7 +754,7 @@ static int run_threshold(arucohip_handle* h, hipStream_t s, const uint8_t* gray_
     const Buffers& b = h->buf;
     h->thres_bytes = true;
     if (dp.thres_method != ARUCOHIP_THRES_CANNY) {
-        const bool lazy = launch_threshold(s, gray_dev, g, nframes, dp, b, b.tune.thres_lazy && !want_bytes && !h->params.erode);
+        const bool lazy = launch_threshold(s, gray_dev, g, nframes, dp, b, b.tune.thres_lazy && !want_bytes);
         h->thres_bytes = !lazy;
         return ARUCOHIP_OK;
     }
@@ -790,9 +790,14 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         if (rc_) return rc_;
     }
     if (h->params.erode) {
-        int rc_ = grow(h, &h->d_erode, &h->erode_bytes, (size_t)nframes * dp.nthr * g.width * g.height);
+        // on the bit tiles where the byte image was left out (the default path), on the bytes otherwise
+        const bool on_tiles = !h->thres_bytes;
+        int rc_ = grow(h, &h->d_erode, &h->erode_bytes, on_tiles ? erode_tiles_tmp_bytes(g, nframes * dp.nthr) : (size_t)nframes * dp.nthr * g.width * g.height);
         if (rc_) return rc_;
-        launch_erode(s, g, nframes * dp.nthr, b, h->d_erode);
+        if (on_tiles)
+            launch_erode_tiles(s, g, nframes * dp.nthr, b, h->d_erode);
+        else
+            launch_erode(s, g, nframes * dp.nthr, b, h->d_erode);
     }
     if (h->ev_thr) HIPCHK(h, hipEventRecord(h->ev_thr, s));
     MARK(K_FILTER);

@@ -210,6 +210,8 @@ void launch_remap(hipStream_t s, const uint8_t* src, size_t row_stride, size_t f
                   const uint16_t* fxy, uint8_t* dst);
 int launch_canny(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, int nthr, const Buffers& b, uint64_t* surv, uint64_t* edge, uint32_t* changed);
 void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);
+size_t erode_tiles_tmp_bytes(const FrameGeom& g, int nplanes);
+void launch_erode_tiles(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp);   // on the lazy byte image (tiles + border lines)
 void launch_tile_bitmap(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b);
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b);
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, int min_contour = 0);

@@ -940,6 +940,102 @@ void launch_erode(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers&
     (void)hipMemcpyAsync(b.thres, tmp, (size_t)nplanes * W * H, hipMemcpyDeviceToDevice, s);
 }
 
+// The same erosion on the lazy byte image (round 3): the thresholded planes exist as 8x8-pixel bit tiles (frame cleared) + their four border
+// lines, and a 3x3 minimum of a binary image is an AND of nine shifted copies - 64 pixels per 64-bit operation, nothing leaves the bit domain and the byte
+// image stays unwritten. One thread per tile: the tile and its eight neighbours with the frame pixels put back from the border lines, pixels outside the
+// image read as set (they do not erode); out: the eroded tile with the frame cleared again and, from the threads on the frame, the eroded border lines.
+struct ErodeArgs {
+    const uint64_t* tiles;
+    const uint8_t* edge;
+    uint64_t* out_tiles;
+    uint8_t* out_edge;
+    int W, H, tnx, tny;
+};
+__device__ __forceinline__ uint64_t erode_full_tile(const ErodeArgs& a, const uint64_t* tiles, const uint8_t* e, int tx, int ty) {
+    const int ntx = (a.W + 7) >> 3, nty = (a.H + 7) >> 3;
+    if (tx < 0 || ty < 0 || tx >= ntx || ty >= nty) return ~0ull;           // outside the image: does not erode
+    const uint64_t COL0 = 0x0101010101010101ull;
+    uint64_t t = tiles[(size_t)ty * a.tnx + tx];
+    const size_t Wp = thres_edge_wp(a.W), Hp = thres_edge_hp(a.H);
+    // the frame pixels (cleared in the tiles) from the border lines: a line byte is 0 or 255
+    auto row_bits = [&](const uint8_t* line) -> uint64_t {                  // 8 bytes -> 8 bits
+        const uint64_t v = *(const uint64_t*)(line + 8 * tx) & COL0;
+        return (v * 0x0102040810204080ull) >> 56;
+    };
+    auto col_bits = [&](const uint8_t* line, int c) -> uint64_t {           // 8 bytes (one per row) -> bit c of every row byte
+        return (*(const uint64_t*)(line + 8 * ty) & COL0) << c;
+    };
+    if (ty == 0) t |= row_bits(e);
+    if (ty == (a.H - 1) >> 3) t |= row_bits(e + Wp) << (8 * ((a.H - 1) & 7));
+    if (tx == 0) t |= col_bits(e + 2 * Wp, 0);
+    if (tx == (a.W - 1) >> 3) t |= col_bits(e + 2 * Wp + Hp, (a.W - 1) & 7);
+    // pixels of the tile beyond the image's last column / row: set
+    const int vc = min(8, a.W - 8 * tx), vr = min(8, a.H - 8 * ty);
+    const uint64_t valid = (((1ull << vc) - 1ull) & 0xFFull) * COL0 & (vr >= 8 ? ~0ull : ((1ull << (8 * vr)) - 1ull));
+    return t | ~valid;
+}
+__global__ __launch_bounds__(256) void erode_tiles_kernel(ErodeArgs a) {
+    const int tx = blockIdx.x * blockDim.x + threadIdx.x, ty = blockIdx.y, plane = blockIdx.z;
+    const int ntx = (a.W + 7) >> 3, nty = (a.H + 7) >> 3;
+    if (tx >= a.tnx) return;
+    const size_t tplane = (size_t)plane * a.tnx * a.tny, eplane = (size_t)plane * thres_edge_stride(a.W, a.H);
+    uint64_t* out = a.out_tiles + tplane + (size_t)ty * a.tnx + tx;
+    if (tx >= ntx || ty >= nty) {   // the pad column / row of the tile array
+        *out = 0ull;
+        return;
+    }
+    const uint64_t* tiles = a.tiles + tplane;
+    const uint8_t* e = a.edge + eplane;
+    const uint64_t COL0 = 0x0101010101010101ull, COL7 = 0x8080808080808080ull;
+    auto hmin = [&](int y) -> uint64_t {   // tile (tx, y) ANDed with its left and right neighbours, column-wise
+        const uint64_t X = erode_full_tile(a, tiles, e, tx, y), L = erode_full_tile(a, tiles, e, tx - 1, y), R = erode_full_tile(a, tiles, e, tx + 1, y);
+        return X & (((X << 1) & ~COL0) | ((L >> 7) & COL0)) & (((X >> 1) & ~COL7) | ((R << 7) & COL7));
+    };
+    const uint64_t hC = hmin(ty), hN = hmin(ty - 1), hS = hmin(ty + 1);
+    uint64_t E = hC & ((hC << 8) | (hN >> 56)) & ((hC >> 8) | (hS << 56));
+    const int vc = min(8, a.W - 8 * tx), vr = min(8, a.H - 8 * ty);
+    E &= (((1ull << vc) - 1ull) & 0xFFull) * COL0 & (vr >= 8 ? ~0ull : ((1ull << (8 * vr)) - 1ull));
+    // the eroded border lines, then the frame cleared for the contour stage
+    const size_t Wp = thres_edge_wp(a.W), Hp = thres_edge_hp(a.H);
+    uint8_t* oe = a.out_edge + eplane;
+    uint64_t frame = 0;
+    if (ty == 0) {
+        for (int c = 0; c < vc; c++) oe[8 * tx + c] = (uint8_t)(((E >> c) & 1ull) * 255u);
+        frame |= 0xFFull;
+    }
+    if (ty == (a.H - 1) >> 3) {
+        const int r = (a.H - 1) & 7;
+        for (int c = 0; c < vc; c++) oe[Wp + 8 * tx + c] = (uint8_t)(((E >> (8 * r + c)) & 1ull) * 255u);
+        frame |= 0xFFull << (8 * r);
+    }
+    if (tx == 0) {
+        for (int r = 0; r < vr; r++) oe[2 * Wp + 8 * ty + r] = (uint8_t)(((E >> (8 * r)) & 1ull) * 255u);
+        frame |= COL0;
+    }
+    if (tx == (a.W - 1) >> 3) {
+        const int c = (a.W - 1) & 7;
+        for (int r = 0; r < vr; r++) oe[2 * Wp + Hp + 8 * ty + r] = (uint8_t)(((E >> (8 * r + c)) & 1ull) * 255u);
+        frame |= COL0 << c;
+    }
+    *out = E & ~frame;
+}
+
+// tiles + border lines -> eroded tiles + border lines (through `tmp`, which holds both), bitmap rebuilt; the byte image stays lazy
+size_t erode_tiles_tmp_bytes(const FrameGeom& g, int nplanes) {
+    return (size_t)nplanes * ((size_t)tiles_x(g.width) * tiles_y(g.height) * sizeof(uint64_t) + thres_edge_stride(g.width, g.height)) + 64;
+}
+void launch_erode_tiles(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, uint8_t* tmp) {
+    ErodeArgs a;
+    a.W = g.width, a.H = g.height, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height);
+    const size_t tile_bytes = (size_t)nplanes * a.tnx * a.tny * sizeof(uint64_t), edge_bytes = (size_t)nplanes * thres_edge_stride(g.width, g.height);
+    a.tiles = b.tiles, a.edge = b.thres_edge, a.out_tiles = (uint64_t*)tmp, a.out_edge = tmp + tile_bytes;
+    (void)hipMemsetAsync(a.out_edge, 0, edge_bytes, s);
+    hipLaunchKernelGGL(erode_tiles_kernel, dim3((a.tnx + 255) / 256, a.tny, nplanes), dim3(256), 0, s, a);
+    (void)hipMemcpyAsync(b.tiles, a.out_tiles, tile_bytes, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(b.thres_edge, a.out_edge, edge_bytes, hipMemcpyDeviceToDevice, s);
+    launch_tile_bitmap(s, g, nplanes, b);
+}
+
 // detectRectangles on a caller-supplied thresholded image (markerdetector.h:261): only the tiled binary image.
 void launch_binary_planes(hipStream_t s, const uint8_t* thres_in, const FrameGeom& g, int nframes, const Buffers& b) {
     dim3 grid((g.width + STRIP - 1) / STRIP, (g.height + SEG - 1) / SEG, nframes);

@@ -64,6 +64,34 @@ def test_erosion_flag(env):
             h.close()
 
 
+def test_erosion_on_tiles_equals_erosion_on_bytes(env, monkeypatch):
+    """Round 3: with the byte image left as bit tiles + border lines (the default) the erosion runs on the tiles (64 pixels per 64-bit
+    AND); with ARUCOHIP_THRES_BYTES=1 it runs on the bytes as before. Both equal numpy's 3x3 minimum, also where the image is not a whole
+    number of tiles and where the frame pixels (kept in the border lines) are set."""
+    capi, orc = env["capi"], env["orc"]
+    fr, _ = env["synth"].make_stream(1, width=1920, height=1080, seed=5, device="cuda")
+    full = fr[0].cpu().numpy()
+    rng = np.random.default_rng(11)
+    noisy = np.clip(full[:757, :1008].astype(np.int32) + rng.integers(-40, 40, (757, 1008)), 0, 255).astype(np.uint8)   # dark specks on the frame too
+    for g in (full, np.ascontiguousarray(full[:757, :1008]), noisy, np.ascontiguousarray(full[100:612, 200:840])):
+        hgt, wid = g.shape
+        want = erode3x3(orc.adaptive_threshold(g, 7, 7.0))
+        results = []
+        for env_bytes in ("0", "1"):
+            monkeypatch.setenv("ARUCOHIP_THRES_BYTES", env_bytes)
+            h = capi.Handle(wid, hgt, max_batch=1)
+            try:
+                p = h.get_params()
+                p.erode = 1
+                h.set_params(p)
+                m = h.detect(g)
+                assert np.array_equal(h.thresholded(0, g.shape), want), (g.shape, env_bytes)
+                results.append((m.tobytes(), [(c["hole"], c["pts"].tobytes()) for c in h.debug_contours(0)]))
+            finally:
+                h.close()
+        assert results[0] == results[1], g.shape
+
+
 def test_frame_undistort_bit_exact(env):
     """Row f3: cv::undistort on the device (map kernel + remap kernel) equals the CPU restatement byte for byte — gray and
     3-channel frames, 4 / 5 / 8 distortion coefficients, a batch, and a frame whose map leaves the image on every side; then
