@@ -312,15 +312,7 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
         }
         return q;
     };
-#ifdef CAND_CLOCK   // debug build only: where the wave's time goes (clock64 ticks), printed by wave (0, plane 0)
-    long long cc_eval = 0, cc_t0 = clock64();
-    int cc_rounds = 0, cc_iters = 0, cc_tiles = 0;
-#endif
     auto evaluate = [&](bool live, const TileSet& q) {
-#ifdef CAND_CLOCK
-        const long long cc_e0 = clock64();
-        cc_rounds++, cc_tiles += __popcll(__ballot(live));
-#endif
         if (live) {
             const int ty = q.ty, tx = q.tx;
             const uint64_t T = q.T, L = q.L, U = q.U, UL = q.UL, UR = q.UR, Rt = q.Rt;
@@ -343,13 +335,6 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
             }
             const uint32_t base = ((uint32_t)(8 * ty) << 16) | (uint32_t)(8 * tx);
             uint64_t m = outer | hole;
-#ifdef CAND_CLOCK
-            {
-                int mx = __popcll(m);
-                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-                cc_iters += mx;
-            }
-#endif
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
@@ -370,9 +355,6 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
         }
         __syncthreads();
         if (max(s_n[0], s_n[1]) > CS_CAP - 64) flush();   // wave-uniform: room for another round's typical yield
-#ifdef CAND_CLOCK
-        cc_eval += clock64() - cc_e0;
-#endif
     };
 
     // The wave's tile rows are ty = blockIdx.x, + gridDim.x, ...; the bitmap words of a row and of the row above it (2 * nstrips each)
@@ -424,11 +406,6 @@ __global__ __launch_bounds__(64) void candidates_sparse_kernel(SparseArgs a) {
         if (qn > 64) evaluate(l1, q1);
     }
     flush();
-#ifdef CAND_CLOCK
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
-        printf("CAND_CLOCK rows of this wave %d: rounds %d tiles %d longest start loops %d | ticks all %lld of which evaluating %lld\n", (nty + (int)gridDim.x - 1) / (int)gridDim.x, cc_rounds,
-               cc_tiles, cc_iters, clock64() - cc_t0, cc_eval);
-#endif
 }
 
 void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, const Buffers& b, int min_contour) {
