@@ -25,8 +25,10 @@ import time
 # Measured: config 2 at depth 3 = 309.7k fps with 4 queues, 343.8k with 8, 320-331k with 16 (more kernels share the chip at once and
 # all of them stretch); config 4 = 56.0k with 8 queues at depth 3 (two workers' border walks shared a queue), 73.8k with 12 or more,
 # 94.4k with 16 queues and six batches in flight (its batches wait on one 5000-step border walk each).
+# Round 3 (shorter kernels: the batches' dependent chains show again): the driver's 20-step run at depth 3 / 8 queues 463-465k, 4 / 12 471-480k, 5 / 12 483-487k,
+# 6 / 16 470-477k (a deeper pipeline also fills and drains longer inside the timed region); 40 steps: 3 / 8 460-470k, 4 / 12 482k, 6 / 16 497k, 8 / 24 491k.
 def default_hw_queues(config):
-    return "16" if config == 4 else "8"
+    return "16" if config == 4 else "12"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -281,7 +283,7 @@ def main():
     ap.add_argument("--host-frames", action="store_true", help="frames start in pinned host memory (PCIe-inclusive rate)")
     ap.add_argument("--clutter", action="store_true", help="robustness leg: textured backgrounds behind the markers (not the headline)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time; default 3, "
+                    help="batches in flight (arucohip_detect_batch_submit / _wait); 1 = one synchronous-style batch at a time; default 5, "
                          "config 4: 6 (its 128-frame batches wait on a 5000-step border walk: more of them in flight fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
@@ -356,7 +358,7 @@ def main():
     # so nothing the gather does can hold up a batch
     lib_stream = torch.cuda.Stream(device=dev)
     handle.set_stream(lib_stream.cuda_stream)
-    depth = args.depth if args.depth > 0 else (6 if args.config == 4 else 3)
+    depth = args.depth if args.depth > 0 else (6 if args.config == 4 else 5)
     outs = [torch.zeros((B, CAP * 96), dtype=torch.uint8, device=dev) for _ in range(depth)]
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
     out, cnt = outs[0], cnts[0]
@@ -600,10 +602,10 @@ def main():
             del frames, outs, cnts, out, cnt
             torch.cuda.empty_cache()
             oc = {}
-            for key, extra in (("config3_fps", ["--config", "3", "--steps", "12", "--warmup", "3"]),
+            for key, extra in (("config3_fps", ["--config", "3", "--steps", "20", "--warmup", "5"]),    # like the headline: five batches in flight fill and drain inside the timed steps
                                ("config4_fps", ["--config", "4", "--steps", "30", "--warmup", "6"]),   # 128-frame batches, six in flight: 12 steps are two rounds
                                ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "6", "--warmup", "2"]),
-                               ("config2_clutter_fps", ["--clutter", "--batch", "256", "--frames", "256", "--steps", "12", "--warmup", "3"])):
+                               ("config2_clutter_fps", ["--clutter", "--batch", "256", "--frames", "256", "--steps", "20", "--warmup", "5"])):
                 d = run_leg(extra)
                 if "error" in d:
                     oc[key] = None
