@@ -78,6 +78,9 @@ struct arucohip_handle {
     size_t gray_bytes = 0;
     uint8_t* d_bgr = nullptr;         // staging for host BGR frames
     size_t bgr_bytes = 0;
+    arucohip_marker_t* wt_out = nullptr;   // set around detect_core by chunk_enqueue: finalize_kernel writes the results there too
+    int32_t* wt_n = nullptr;
+    int wt_cap = 0;
     uint8_t* d_erode = nullptr;       // eroded planes (params.erode)
     size_t erode_bytes = 0;
     uint8_t* d_canny = nullptr;       // CANNY: survivor tiles, edge tiles, changed flag
@@ -842,7 +845,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
     }
     MARK(K_FINALIZE);
-    if (stop > 8) launch_finalize(s, g, nframes, dp, cam, b);
+    if (stop > 8) launch_finalize(s, g, nframes, dp, cam, b, h->wt_out, h->wt_cap, h->wt_n);
     MARK(K_POSE);
     if (stop > 8 && cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
     MARK(K_COUNT);
@@ -917,7 +920,13 @@ static int chunk_enqueue(arucohip_handle* w, const uint8_t* frames, int nframes,
     const uint8_t* gray_dev;
     FrameGeom g;
     if ((rc = stage_frames(w, frames, nframes, W, H, row_stride, frame_stride, frames_on_device, channels, &gray_dev, &g))) return rc;
-    if ((rc = detect_core(w, gray_dev, g, nframes, dp, cam))) return rc;
+    // results for device memory without poses: finalize_kernel stores them there itself
+    const bool write_through = out_on_device && !(cam.has_K && cam.marker_size > 0) && cap > 0;
+    w->wt_out = write_through ? out : nullptr, w->wt_cap = write_through ? cap : 0, w->wt_n = write_through ? n_out : nullptr;
+    rc = detect_core(w, gray_dev, g, nframes, dp, cam);
+    w->wt_out = nullptr, w->wt_cap = 0, w->wt_n = nullptr;
+    if (rc) return rc;
+    if (write_through) return ARUCOHIP_OK;
     const Buffers& b = w->buf;
     const int ncopy = std::min(cap, b.cap_markers);
     if (out_on_device) {

@@ -232,7 +232,8 @@ void launch_set_decoded(hipStream_t s, const Buffers& b, uint32_t n, const int2*
 void launch_refine_lines(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b, bool fused_cells = false);
 void launch_locked_corners(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
 void launch_refine_pixels(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);
-void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b);
+void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b, arucohip_marker_t* out = nullptr,
+                     int out_cap = 0, int32_t* n_out = nullptr);   // out / n_out: the caller's device arrays, written as well (no pose to add later)
 void launch_pose(hipStream_t s, int nframes, const CamModel& cam, const Buffers& b);
 void launch_warp_only(hipStream_t s, const uint8_t* gray, const FrameGeom& g, const float* quad_dev, int size, uint8_t* dst_dev);
 void launch_pnp_points(hipStream_t s, const float* obj, const float* img, int npts, const CamModel& cam, double* rt_out, int* ok_out);

@@ -32,6 +32,11 @@ struct FinalArgs {
     int nthr;
     int cap_cands, cap_markers;
     int bx0, by0, bx1, by1;
+    // write-through (round 3): results that go to the caller's device memory and need no pose are stored there by this kernel as well,
+    // instead of two copies queued behind it (each a dispatch that waits its turn on a busy chip: 0.1 ms apiece with five batches in flight)
+    arucohip_marker_t* out;   // [frames][out_cap] or null
+    int32_t* n_out;           // [frames] or null
+    int out_cap;
 };
 
 __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
                 m.ssize = -1.f, m.has_pose = 0, m.pad_ = 0;
                 for (int k = 0; k < 3; k++) m.rvec[k] = m.tvec[k] = 0;
                 M[n] = m;
+                if (a.out && n < a.out_cap) a.out[(size_t)frame * a.out_cap + n] = m;
             }
             n++;
         }
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
         for (int t = 0; t < a.nthr; t++) fst |= a.trig_cnt[(size_t)(frame * a.nthr + t) * TRIG_CNT_STRIDE + TC_STATUS];
         if (fst) n = -1;
         a.nmarkers[frame] = n;   // required count; the host clamps and reports ARUCOHIP_E_CAPACITY
+        if (a.n_out) a.n_out[frame] = n;
         // work list of the pose kernel (order across frames is irrelevant); never more than F * cap_markers entries
         const int kept = min(n, a.cap_markers);
         if (kept > 0) {
@@ -111,8 +118,10 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
     }
 }
 
-void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b) {
+void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const CamModel& cam, const Buffers& b, arucohip_marker_t* out, int out_cap,
+                     int32_t* n_out) {
     FinalArgs a;
+    a.out = out, a.out_cap = out_cap, a.n_out = n_out;
     a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters, a.marker_list = b.marker_list;
     a.trig_cnt = b.trig_cnt, a.nthr = p.nthr;
     a.cap_cands = b.cap_cands, a.cap_markers = b.cap_markers;
