@@ -74,6 +74,7 @@ SYMBOLS = [
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
     "arucohip_mgpu_set_depth", "arucohip_mgpu_submit_batch", "arucohip_mgpu_submit_streams", "arucohip_mgpu_wait",
     "arucohip_compact_bytes", "arucohip_compact_markers", "arucohip_wait_event", "arucohip_detect_batch_retry_overflowed",
+    "arucohip_refine_candidate_lines",
 ]
 
 _lib = None
@@ -84,7 +85,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = library_path()
+    # ARUCOHIP_LIB: an experiment's variant build (tools/ab_variants.sh, tools/stage_cost.sh) is loaded from its own path; the product
+    # library in the tree is never overwritten
+    path = os.environ.get("ARUCOHIP_LIB") or library_path()
     if "torch" not in sys.modules:
         # One HIP runtime per process: torch ships its own libamdhip64.so.7; when torch is importable load it first so
         # that libarucohip binds to the same runtime (two runtimes in one process cannot both own the GPU).
@@ -166,6 +169,7 @@ def load():
     L.arucohip_compact_markers.argtypes = [vp, vp, i, i, vp, i, vp]
     L.arucohip_wait_event.argtypes = [vp, vp]
     L.arucohip_detect_batch_retry_overflowed.argtypes = [vp, vp, i, i, i, sz, sz, i, vp, vp, i, f, i, vp, i, vp, i, vp]
+    L.arucohip_refine_candidate_lines.argtypes = [vp, vp, i, vp, vp, vp, i]
     L.arucohip_default_params.argtypes = [vp]
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
@@ -316,6 +320,14 @@ class Handle:
         self._chk(self.L.arucohip_undistort(self.h, _ptr(a), n, wid, hgt, wid * cn, wid * hgt * cn, cn, 0, _ptr(Ka), _ptr(da),
                                             0 if da is None else da.size, _ptr(out), 0))
         return out
+
+    def refine_candidate_lines(self, contour, corners, K=None, dist=None):
+        """MarkerDetector::refineCandidateLines: contour = n x 2 integer points, corners = 4 x 2; returns the refined corners (4 x 2)."""
+        xy = np.ascontiguousarray(contour, dtype=np.int32).reshape(-1, 2)
+        c = np.ascontiguousarray(corners, dtype=np.float32).reshape(8).copy()
+        Ka, da = _f32(K), _f32(dist)
+        self._chk(self.L.arucohip_refine_candidate_lines(self.h, _ptr(xy), len(xy), _ptr(c), _ptr(Ka), _ptr(da), 0 if da is None else da.size))
+        return c.reshape(4, 2)
 
     def bgr_to_gray(self, bgr):
         b = np.ascontiguousarray(bgr, dtype=np.uint8)

@@ -1419,6 +1419,54 @@ int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int W, int H, size_t 
     return ARUCOHIP_OK;
 }
 
+// MarkerDetector::refineCandidateLines (markerdetector.cpp:931-997) on a caller-supplied contour: the contour becomes border 0 of plane 0, the
+// corners candidate 0 of frame 0, and one wave of refine_lines_kernel does what it does for a decoded candidate of a batch.
+int arucohip_refine_candidate_lines(arucohip_handle* h, const int32_t* contour_xy, int npoints, float corners[8], const float* K, const float* dist, int ndist) {
+    if (!h || !contour_xy || !corners || npoints < 1) return ARUCOHIP_E_INVALID;
+    if ((uint32_t)npoints > h->buf.cap_pool) return fail(h, ARUCOHIP_E_CAPACITY, "contour longer than the handle's point list (points_per_frame)");
+    HIPCHK(h, hipSetDevice(h->device));
+    CamModel cam;
+    int rc = make_cam(h, K, dist, ndist, -1.f, 0, &cam);
+    if (rc) return rc;
+    std::vector<short2> pts((size_t)npoints);
+    for (int i = 0; i < npoints; i++) {
+        const int32_t x = contour_xy[2 * i], y = contour_xy[2 * i + 1];
+        if (x < 0 || y < 0 || x > 32767 || y > 32767) return fail(h, ARUCOHIP_E_INVALID, "contour point outside 0..32767");
+        pts[i] = make_short2((short)x, (short)y);
+    }
+    ContourDesc cd{};
+    cd.plane = 0, cd.x0 = pts[0].x, cd.y0 = pts[0].y, cd.hole = 0, cd.n = npoints, cd.key = 0, cd.pool_off = 0, cd.ck_off = 0xFFFFFFFFu;
+    Cand c{};
+    for (int k = 0; k < 4; k++) {
+        c.c[2 * k] = corners[2 * k], c.c[2 * k + 1] = corners[2 * k + 1];
+        // Point(candidate[k]): cv::Point2f -> cv::Point rounds to nearest, ties to even (saturate_cast<int>(float) = cvRound)
+        const long qx = lrintf(corners[2 * k]), qy = lrintf(corners[2 * k + 1]);
+        c.qx[k] = (int16_t)std::min<long>(std::max<long>(qx, -32768), 32767), c.qy[k] = (int16_t)std::min<long>(std::max<long>(qy, -32768), 32767);
+    }
+    c.cdesc = 0, c.swapped = 0, c.id = 0, c.nrot = 0;
+    DetectParams dp;
+    std::memset(&dp, 0, sizeof(dp));
+    dp.nthr = 1, dp.corner_method = ARUCOHIP_CORNER_LINES, dp.warp_size = h->params.warp_size, dp.decoder = ARUCOHIP_DECODER_USER;   // ids are given: no cell decode
+    hipStream_t s = h->stream;
+    const Buffers& b = h->buf;
+    const uint32_t one = 1, entry = 0;
+    HIPCHK(h, hipMemsetAsync(h->zero_block, 0, h->zero_words * sizeof(uint32_t), s));
+    HIPCHK(h, hipMemcpyAsync(b.pool, pts.data(), pts.size() * sizeof(short2), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.cdesc, &cd, sizeof(cd), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.cands, &c, sizeof(c), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.cand_list, &entry, sizeof(entry), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.counters + CNT_NCAND, &one, sizeof(one), hipMemcpyHostToDevice, s));
+    FrameGeom g{};
+    g.width = h->lim.max_width, g.height = h->lim.max_height;
+    launch_refine_lines(s, g, 1, dp, cam, b, false);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(&c, b.cands, sizeof(c), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int k = 0; k < 8; k++) corners[k] = c.c[k];
+    h->last_frames = 0;   // the lists no longer hold a batch
+    return ARUCOHIP_OK;
+}
+
 int arucohip_board_detect_batch(arucohip_handle* h, int nframes, const int32_t* ids, const float* obj, int nboard, int info_type, const float* K,
                                 const float* dist, int ndist, float marker_size, float repj_err_thres, int y_perp, arucohip_board_t* out, float* prob) {
     if (!h || !out || !prob) return ARUCOHIP_E_INVALID;

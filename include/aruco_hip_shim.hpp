@@ -52,6 +52,10 @@ struct Point3f {
     float x, y, z;
     Point3f(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {}
 };
+struct Point {   // cv::Point = Point_<int>: contour points (MarkerCandidate::contour)
+    int x, y;
+    Point(int x_ = 0, int y_ = 0) : x(x_), y(y_) {}
+};
 struct Size {
     int width, height;
     Size(int w = 0, int h = 0) : width(w), height(h) {}
@@ -367,6 +371,12 @@ public:
     }
     void glGetModelViewMatrix(double modelview_matrix[16]) const { arucohip_gl_modelview_(Rvec, Tvec, modelview_matrix); }              // marker.h:90
     void OgreGetPoseParameters(double position[3], double orientation[4]) const { arucohip_ogre_pose_(Rvec, Tvec, position, orientation); }  // marker.h:104
+#if ARUCOHIP_HAVE_OPENCV
+    // marker.h:69. Drawing is outside the detection path: the member is DECLARED so that the reference's callers compile
+    // (utils/aruco_simple.cpp:82); its definition stays the reference's own cv::line / cv::putText code (src/marker.cpp:54-81), which needs
+    // nothing but OpenCV imgproc and this class - INTEGRATION.md "drawing".
+    void draw(cv::Mat& in, cv::Scalar color, int lineWidth = 1, bool writeId = true) const;
+#endif
     friend bool operator<(const Marker& a, const Marker& b) { return a.id < b.id; }
     friend std::ostream& operator<<(std::ostream& str, const Marker& M) {  // marker.h:128-139
         str << M.id << "=";
@@ -541,6 +551,15 @@ public:
 
 class MarkerDetector {
 public:
+    // markerdetector.h:45-62: a candidate to be a marker = the marker (corners, id) + its contour + its position in the contour list.
+    // (Private in the reference although refineCandidateLines, a public member, takes one; public here so that a caller can build one.)
+    class MarkerCandidate : public Marker {
+    public:
+        MarkerCandidate() : idx(-1) {}
+        MarkerCandidate(const Marker& M) : Marker(M), idx(-1) {}
+        std::vector<cv::Point> contour;   // all the points of its contour
+        int idx;                          // index position in the global contour list
+    };
     enum ThresholdMethods { FIXED_THRES, ADPT_THRES, CANNY };
     enum CornerRefinementMethod { NONE, HARRIS, SUBPIX, LINES };
 
@@ -691,6 +710,24 @@ public:
         for (int k = 0; k < 4; k++) q[2 * k] = points[k].x, q[2 * k + 1] = points[k].y;
         out = cv::Mat(size.height, size.width, CV_8UC1);
         arucohip_throw_(arucohip_warp(h_, in.data, in.cols, in.rows, in.step, q, size.width, out.data), "warp", h_);
+    }
+    // markerdetector.h:280 / markerdetector.cpp:931-997: the LINES corner refinement of one candidate, on the device
+    // (arucohip_refine_candidate_lines): the four corners become the intersections of the least-squares lines through the contour's sides;
+    // with both matrices non-empty the contour is undistorted first and the corners are distorted again.
+    void refineCandidateLines(MarkerCandidate& candidate, const cv::Mat& camMatrix, const cv::Mat& distCoeff) {
+        if (candidate.size() != 4 || candidate.contour.empty())
+            arucohip_throw_(ARUCOHIP_E_INVALID, "refineCandidateLines: a candidate has 4 corners and a contour", nullptr);
+        ensure_(std::max(cap_w_, 64), std::max(cap_h_, 64));
+        float K[9], d[8], c[8];
+        const bool hasK = mat_to_K_(camMatrix, K);
+        const int nd = mat_to_dist_(distCoeff, d);
+        const bool undist = hasK && nd > 0;   // :958 / :990: both matrices or neither
+        std::vector<int32_t> xy(2 * candidate.contour.size());
+        for (size_t i = 0; i < candidate.contour.size(); i++) xy[2 * i] = candidate.contour[i].x, xy[2 * i + 1] = candidate.contour[i].y;
+        for (int k = 0; k < 4; k++) c[2 * k] = candidate[k].x, c[2 * k + 1] = candidate[k].y;
+        arucohip_throw_(arucohip_refine_candidate_lines(h_, xy.data(), (int)candidate.contour.size(), c, undist ? K : nullptr, undist ? d : nullptr, undist ? nd : 0),
+                        "refineCandidateLines", h_);
+        for (int k = 0; k < 4; k++) candidate[k] = cv::Point2f(c[2 * k], c[2 * k + 1]);
     }
     // Marker::calculateExtrinsics for a whole vector at once (batched device solvePnP)
     void calculateExtrinsics(std::vector<Marker>& markers, float markerSize, cv::Mat camMatrix, cv::Mat distCoeff = cv::Mat(), bool setYPerpendicular = true) {
@@ -894,6 +931,7 @@ public:
     MarkerDetector& getMarkerDetector() { return _mdetector; }
     std::vector<Marker>& getDetectedMarkers() { return _vmarkers; }
     void setYPerpendicular(bool enable) { _setYPerpendicular = enable; }
+    bool isYPerpendicular() { return _setYPerpendicular; }   // boarddetector.h:128
     void set_repj_err_thres(float Repj_err_thres) { repj_err_thres = Repj_err_thres; }
     float get_repj_err_thres() const { return repj_err_thres; }
 

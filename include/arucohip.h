@@ -244,6 +244,17 @@ int arucohip_detect_rectangles(arucohip_handle* h, const uint8_t* thres, int wid
 int arucohip_warp(arucohip_handle* h, const uint8_t* gray, int width, int height, size_t row_stride, const float quad[8],
                   int size, uint8_t* dst);
 
+/* MarkerDetector::refineCandidateLines(MarkerCandidate&, camMatrix, distCoeff) (markerdetector.h:280, .cpp:931-997), the LINES
+ * corner refinement as a stage of its own: contour_xy = the candidate's contour (MarkerCandidate::contour, markerdetector.h:60: npoints
+ * cv::Point = int32 pairs x0,y0,x1,y1,... in the order cv::findContours produced them, reversed if detectRectangles swapped the corners),
+ * corners = the candidate's four corners on input (they must be contour points: every corner is looked up in the contour after rounding
+ * to int like Point(candidate[k]), the last match wins) and the four intersections of the sides' least-squares lines on output. With K
+ * (9 floats) and dist (ndist > 0) the contour is undistorted before the fit and the corners are distorted again, as the reference does
+ * when both matrices are non-empty. Coordinates are image pixels, 0 <= x, y <= 32767; npoints at most the handle's
+ * points_per_frame. Uses the handle's candidate and point lists: results of the last batch are gone afterwards (like the other stage calls). */
+int arucohip_refine_candidate_lines(arucohip_handle* h, const int32_t* contour_xy, int npoints, float corners[8], const float* K,
+                                    const float* dist, int ndist);
+
 /* Stage inspection for parity tests (results of the last detect/detect_batch/detect_rectangles call).
  * Contours that passed the size filter, in the reference's cv::findContours(RETR_LIST) relative order. */
 int arucohip_debug_num_contours(arucohip_handle* h, int frame, int* n);

@@ -239,6 +239,16 @@ def solve_pnp(obj, img, K, dist):
     return bool(ok), np.array(r), np.array(t)
 
 
+def refine_lines(contour, corners, K=None, dist=None):
+    """MarkerDetector::refineCandidateLines on a contour (n x 2 ints) and four corners; returns the refined corners (4 x 2)."""
+    xy = np.ascontiguousarray(contour, dtype=np.int32).reshape(-1, 2)
+    c = np.ascontiguousarray(corners, dtype=np.float32).reshape(8).copy()
+    Ka, Kp = _f32(K)
+    da, dp = _f32(dist)
+    lib().orc_refine_lines(xy.ctypes.data_as(C.c_void_p), len(xy), c.ctypes.data_as(C.c_void_p), Kp, dp, 0 if da is None else da.size)
+    return c.reshape(4, 2)
+
+
 def corner_subpix(gray, pts, win=7, max_iter=8, eps=0.005):
     g, gp = _u8(gray)
     h, w = g.shape

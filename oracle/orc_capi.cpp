@@ -191,6 +191,15 @@ int orc_corner_harris_window(const uint8_t* gray, int w, int h, int stride, int 
     std::memcpy(out, v.data(), v.size() * sizeof(float));
     return (int)v.size();
 }
+// MarkerDetector::refineCandidateLines (src/markerdetector.cpp:931-997) on a caller-supplied contour and corners
+void orc_refine_lines(const int32_t* xy, int n, float* corners8, const float* K, const float* dist, int ndist) {
+    Candidate c;
+    c.contour.resize(n);
+    for (int i = 0; i < n; i++) c.contour[i] = Pt{xy[2 * i], xy[2 * i + 1]};
+    for (int k = 0; k < 4; k++) c.c[k] = Pt2f{corners8[2 * k], corners8[2 * k + 1]};
+    refine_lines(c, K, dist, ndist);
+    for (int k = 0; k < 4; k++) corners8[2 * k] = c.c[k].x, corners8[2 * k + 1] = c.c[k].y;
+}
 float orc_board_detect(const orc_marker_t* ms, int n, const int32_t* ids, const float* obj, int nboard, int info_type,
                        const float* K, const float* dist, int ndist, float marker_size, float repj_thres, int y_perp,
                        orc_marker_t* out_ms, int* n_out, double* rvec, double* tvec, int* has_pose) {

@@ -51,6 +51,14 @@ template <class T> struct Size_ {
     bool operator!=(const Size_& o) const { return !(*this == o); }
 };
 typedef Size_<int> Size;
+template <class T> struct Scalar_ {   // cv::Scalar: four values, the colour argument of the drawing calls
+    T val[4];
+    Scalar_() { val[0] = val[1] = val[2] = val[3] = 0; }
+    Scalar_(T v0, T v1 = 0, T v2 = 0, T v3 = 0) { val[0] = v0, val[1] = v1, val[2] = v2, val[3] = v3; }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+};
+typedef Scalar_<double> Scalar;
 
 class Exception : public std::exception {
 public:
@@ -121,6 +129,17 @@ protected:
     std::shared_ptr<std::vector<uchar> > store_;
 };
 inline MatExpr::operator Mat() const { return Mat(rows, cols, type); }
+inline std::ostream& operator<<(std::ostream& s, const Mat& m) {   // OpenCV prints "[a, b; c, d]"
+    s << "[";
+    for (int r = 0; r < m.rows; r++)
+        for (int c = 0; c < m.cols; c++) {
+            if (m.depth() == CV_64F) s << m.at<double>(r, c);
+            else if (m.depth() == CV_32F) s << m.at<float>(r, c);
+            else s << (int)m.at<uchar>(r, c);
+            s << (c + 1 < m.cols ? ", " : (r + 1 < m.rows ? ";\n " : ""));
+        }
+    return s << "]";
+}
 
 template <class T> struct DataType;
 template <> struct DataType<float> { enum { type = CV_32FC1 }; };

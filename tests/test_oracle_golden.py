@@ -100,3 +100,23 @@ def test_refine_fail_frame():
     assert len(ms) >= 10
     for m in ms:
         assert np.isfinite(m["corners"]).all() and np.isfinite(m["rvec"]).all() and np.isfinite(m["tvec"]).all()
+
+
+def test_refine_lines_as_a_stage_reproduces_the_golden_corners():
+    """MarkerDetector::refineCandidateLines called on its own (src/markerdetector.h:280, .cpp:931-997): contour + integer quad of every
+    decoded candidate of the board and single stills -> the corners of testdata/board/expected.yml / single/expected.yml (the latter with
+    the undistort / distort round trip of :956-959, :989-991)."""
+    for name, with_cam in (("board", False), ("single", True)):
+        gray, doc = load_case(name)
+        K, dist = (doc["intrinsics"]["K"], doc["intrinsics"]["dist"]) if with_cam else (None, None)
+        o = orc.Oracle()
+        o.detect_raw(gray)
+        gold = {m["id"]: np.array(m["corners"]) for m in doc["markers"]}
+        seen = 0
+        for c in o.candidates(with_contour=True):
+            if c["id"] < 0:
+                continue
+            r = orc.refine_lines(c["contour"], c["quad0"], K=K, dist=dist)
+            assert np.max(np.abs(np.roll(r, c["nrot"], axis=0) - gold[c["id"]])) < CORNER_ABS_TOL
+            seen += 1
+        assert seen == len(gold)
