@@ -74,7 +74,7 @@ SYMBOLS = [
     "arucohip_mgpu_set_params", "arucohip_mgpu_last_error_string", "arucohip_mgpu_detect_batch", "arucohip_mgpu_detect_streams",
     "arucohip_mgpu_set_depth", "arucohip_mgpu_submit_batch", "arucohip_mgpu_submit_streams", "arucohip_mgpu_wait",
     "arucohip_compact_bytes", "arucohip_compact_markers", "arucohip_wait_event", "arucohip_detect_batch_retry_overflowed",
-    "arucohip_refine_candidate_lines",
+    "arucohip_refine_candidate_lines", "arucohip_mgpu_gather_mode", "arucohip_build_info",
 ]
 
 _lib = None
@@ -99,6 +99,7 @@ def load():
         raise ArucoHipError(E_HIP, "libarucohip.so is not built (%s); run aruco_amd.build_library()" % path)
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     L.arucohip_last_error_string.restype = C.c_char_p
+    L.arucohip_build_info.restype = C.c_char_p
     L.arucohip_stage_name.restype = C.c_char_p
     L.arucohip_kernel_name.restype = C.c_char_p
     L.arucohip_get_stream.restype = C.c_void_p
@@ -164,6 +165,7 @@ def load():
     L.arucohip_mgpu_submit_batch.argtypes = [vp, vp, i, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp, vp]
     L.arucohip_mgpu_submit_streams.argtypes = [vp, vp, vp, i, i, sz, sz, vp, vp, i, f, i, vp, i, vp, vp]
     L.arucohip_mgpu_wait.argtypes = [vp, i]
+    L.arucohip_mgpu_gather_mode.argtypes = [vp]
     L.arucohip_compact_bytes.argtypes = [i, i]
     L.arucohip_compact_bytes.restype = sz
     L.arucohip_compact_markers.argtypes = [vp, vp, i, i, vp, i, vp]
@@ -174,6 +176,11 @@ def load():
     L.arucohip_default_limits.argtypes = [vp, i, i, i]
     _lib = L
     return L
+
+
+def build_info():
+    """arucohip_build_info(): 'src=<digest> flags=[...]' of the loaded library."""
+    return (load().arucohip_build_info() or b"").decode()
 
 
 def compact_bytes(nframes, cap_total):
@@ -589,6 +596,10 @@ class MultiGpu:
 
     def set_depth(self, depth):
         self._chk(self.L.arucohip_mgpu_set_depth(self.m, int(depth)))
+
+    def gather_mode(self):
+        """GATHER_PEER only if it was asked for and every device reaches the first one; else GATHER_HOST."""
+        return int(self.L.arucohip_mgpu_gather_mode(self.m))
 
     def submit_batch_host(self, frames, K=None, dist=None, marker_size=-1.0, y_perp=False):
         """arucohip_mgpu_submit_batch; returns a job whose arrays stay alive until wait(job)."""

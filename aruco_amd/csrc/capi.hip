@@ -196,6 +196,14 @@ extern "C" {
 
 int arucohip_version(void) { return ARUCOHIP_VERSION; }
 
+#ifndef ARUCOHIP_SRC_HASH
+#define ARUCOHIP_SRC_HASH "unknown"
+#endif
+#ifndef ARUCOHIP_EXTRA_FLAGS
+#define ARUCOHIP_EXTRA_FLAGS ""
+#endif
+const char* arucohip_build_info(void) { return "src=" ARUCOHIP_SRC_HASH " flags=[" ARUCOHIP_EXTRA_FLAGS "]"; }
+
 void arucohip_default_params(arucohip_params_t* p) {
     std::memset(p, 0, sizeof(*p));
     p->thres_method = ARUCOHIP_THRES_ADPT;
@@ -274,6 +282,13 @@ static void free_all(arucohip_handle* h) {
 
 static thread_local bool g_creating_child = false;
 
+// The one-frame handle of arucohip_detect_batch_retry_overflowed copies parameters, dictionary and decoder callback when it is made: whenever
+// one of them changes it is dropped and the next retry builds a fresh one (a stale copy would decode retried frames with the old dictionary).
+static void drop_retry(arucohip_handle* h) {
+    if (h->retry) arucohip_destroy(h->retry);
+    h->retry = nullptr, h->retry_mult = 0;
+}
+
 int arucohip_create_ex(const arucohip_params_t* params, int device, const arucohip_limits_t* lim, arucohip_handle** out) {
     if (!out || !lim) return ARUCOHIP_E_INVALID;
     *out = nullptr;
@@ -344,7 +359,6 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if ((e = hipMemset(b.tiles, 0, bits_bytes)) != hipSuccess) return bail(e);   // pad tiles must read as zero
     ALLOC(b.tile_bits, P * (size_t)tiles_y(lim->max_height) * 2 * tile_strips(lim->max_width) * sizeof(uint64_t));
     h->bits_bytes = bits_bytes;
-    ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
     ALLOC(b.trig, P * (size_t)b.cap_trig * sizeof(uint2));
     {
         // contour pipeline: ARUCOHIP_CONTOURS = walkers | segments; default by handle shape. The per-candidate walkers win on
@@ -360,9 +374,12 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
         while (hs < 2u * b.cap_raw) hs <<= 1;
         b.hash_mask = hs - 1;
     }
-    ALLOC(b.node, P * (size_t)b.cap_raw * sizeof(uint4));
-    ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
-    ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
+    if (b.seg_mode) {   // waypoint-segment pipeline only: a walker handle of 1024 frames would carry 5 GB of these for nothing
+        ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
+        ALLOC(b.node, P * (size_t)b.cap_raw * sizeof(uint4));
+        ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
+        ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
+    }
     ALLOC(b.gen_buf, P * (size_t)b.long_cap * 4 * 20);   // [2 kinds][2 parities][P * long_cap] walk states (16 B) + ring ids (4 B)
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
@@ -451,6 +468,7 @@ int arucohip_set_params(arucohip_handle* h, const arucohip_params_t* p) {
         l->params = *p;
         for (auto* k : l->kids) k->params = *p;
     }
+    drop_retry(h);
     return ARUCOHIP_OK;
 }
 
@@ -813,41 +831,39 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
         MARK(K_CONTOUR_QUADS);
         launch_contour_quads(s, g, nframes, dp, b);
     } else {
-        const int stop = b.tune.stop_after;   // 99 outside the stage-cost experiment
-        if (stop > 1) launch_start_candidates(s, g, nframes * dp.nthr, b, dp.min_contour);
+        if (RUN_STAGE(b.tune, 1)) launch_start_candidates(s, g, nframes * dp.nthr, b, dp.min_contour);
         MARK(K_WALKERS);
         // walkers; their late generations run on the side stream under the first quad pass (the contour_quad mark sits at the fork)
         WalkFork fk{b.tune.walk_fork ? h->side_stream : nullptr, h->ev_wfork, h->ev_wjoin, tm ? ev[K_WALKERS_LONG] : nullptr};
-        const bool forked = stop > 2 ? launch_walkers(s, fk, g, nframes * dp.nthr, dp, b) : false;
+        const bool forked = RUN_STAGE(b.tune, 2) ? launch_walkers(s, fk, g, nframes * dp.nthr, dp, b) : false;
         MARK(K_CONTOUR_QUADS);
-        if (stop > 4) launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
+        if (RUN_STAGE(b.tune, 4)) launch_contour_quads(s, g, nframes, dp, b, forked ? 1 : 0);
         if (forked) {
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_wjoin, 0));
-            if (stop > 4) launch_contour_quads(s, g, nframes, dp, b, 2);
+            if (RUN_STAGE(b.tune, 4)) launch_contour_quads(s, g, nframes, dp, b, 2);
         }
     }
-    const int stop = b.tune.stop_after;
     MARK(K_FRAME_CANDS);
-    if (stop > 5) launch_frame_candidates(s, g, nframes, dp, b);
+    if (RUN_STAGE(b.tune, 5)) launch_frame_candidates(s, g, nframes, dp, b);
     MARK(K_DECODE);
     // built-in 5x5 decoder: the cell votes and the Hamming decode of a candidate are the head of its refinement wave (one dispatch less)
     const bool fused_cells = dp.decoder == ARUCOHIP_DECODER_FIDUCIAL_5X5;
-    if (stop > 6) launch_decode(s, gray_dev, g, nframes, dp, b, fused_cells);
+    if (RUN_STAGE(b.tune, 6)) launch_decode(s, gray_dev, g, nframes, dp, b, fused_cells);
     if (dp.decoder == ARUCOHIP_DECODER_USER) {
         const int rc_ = user_decode_stage(h, dp);
         if (rc_) return rc_;
     }
     MARK(K_REFINE_LINES);
-    if (stop > 7) launch_refine_lines(s, g, nframes, dp, cam, b, fused_cells);
+    if (RUN_STAGE(b.tune, 7)) launch_refine_lines(s, g, nframes, dp, cam, b, fused_cells);
     MARK(K_REFINE_PIXELS);
     if (dp.corner_method == ARUCOHIP_CORNER_HARRIS || dp.corner_method == ARUCOHIP_CORNER_SUBPIX) {
         if (dp.locked) launch_locked_corners(s, gray_dev, g, nframes, dp, b);   // markerdetector.cpp:398-399
         launch_refine_pixels(s, gray_dev, g, nframes, dp, b);
     }
     MARK(K_FINALIZE);
-    if (stop > 8) launch_finalize(s, g, nframes, dp, cam, b, h->wt_out, h->wt_cap, h->wt_n);
+    if (RUN_STAGE(b.tune, 8)) launch_finalize(s, g, nframes, dp, cam, b, h->wt_out, h->wt_cap, h->wt_n);
     MARK(K_POSE);
-    if (stop > 8 && cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
+    if (RUN_STAGE(b.tune, 8) && cam.has_K && cam.marker_size > 0) launch_pose(s, nframes, cam, b);
     MARK(K_COUNT);
 #undef MARK
     if (tm) h->tsets++;
@@ -894,9 +910,14 @@ static int stage_frames(arucohip_handle* h, const uint8_t* frames, int nframes, 
         return ARUCOHIP_OK;
     }
     if ((rc = grow(h, &h->d_gray, &h->gray_bytes, (size_t)nframes * W * H))) return rc;
-    for (int f = 0; f < nframes; f++)
-        HIPCHK(h, hipMemcpy2DAsync(h->d_gray + (size_t)f * W * H, W, frames + (size_t)f * frame_stride, row_stride, W, H,
-                                   hipMemcpyHostToDevice, h->stream));
+    if (row_stride == (size_t)W && frame_stride == (size_t)W * H) {
+        // tightly packed frames (a pinned ring of camera frames): ONE copy for the batch instead of one 2-D copy per frame
+        HIPCHK(h, hipMemcpyAsync(h->d_gray, frames, (size_t)nframes * W * H, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < nframes; f++)
+            HIPCHK(h, hipMemcpy2DAsync(h->d_gray + (size_t)f * W * H, W, frames + (size_t)f * frame_stride, row_stride, W, H,
+                                       hipMemcpyHostToDevice, h->stream));
+    }
     *gray_dev = h->d_gray;
     g->row_stride = W, g->frame_stride = (size_t)W * H;
     return ARUCOHIP_OK;
@@ -1122,6 +1143,7 @@ int arucohip_undistort(arucohip_handle* h, const uint8_t* src, int nframes, int 
 
 int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t* codes, int tau0, float correction_rate) {
     if (!h) return ARUCOHIP_E_INVALID;
+    drop_retry(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->d_hrm) HIPCHK(h, hipFree(h->d_hrm));
@@ -1145,6 +1167,7 @@ int arucohip_set_dictionary(arucohip_handle* h, int n, int count, const uint64_t
 
 int arucohip_set_decoder_callback(arucohip_handle* h, arucohip_decoder_fn fn, void* user) {
     if (!h) return ARUCOHIP_E_INVALID;
+    drop_retry(h);
     h->decoder_fn = fn, h->decoder_user = user;
     for (auto* k : h->kids) k->decoder_fn = fn, k->decoder_user = user;
     for (auto* l : h->lanes) arucohip_set_decoder_callback(l, fn, user);
@@ -1736,7 +1759,9 @@ int arucohip_detect_batch_retry_overflowed(arucohip_handle* h, const uint8_t* fr
         int32_t got = 0;
         int rc = ARUCOHIP_E_OVERFLOW;
         for (int attempt = 0; attempt < 3 && rc == ARUCOHIP_E_OVERFLOW; attempt++) {
-            const int want = h->retry ? (attempt == 0 ? h->retry_mult : h->retry_mult * 4) : 4;
+            // 4x, 16x, 64x the batch handle's lists and never more: a cached handle is reused at its size, a frame that overflows 64x is reported
+            const int want = h->retry ? std::min(64, attempt == 0 ? h->retry_mult : h->retry_mult * 4) : 4;
+            if (attempt > 0 && h->retry && want == h->retry_mult) break;   // already at the cap
             if (!h->retry || want != h->retry_mult) {
                 if (h->retry) arucohip_destroy(h->retry);
                 h->retry = nullptr;

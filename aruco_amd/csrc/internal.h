@@ -129,11 +129,20 @@ struct Tuning {
     int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
     int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
-    int stop_after = 99;       // stage-cost experiment (tools/stage_cost.sh; only a library built with -DARUCOHIP_STAGE_EXPERIMENT reads ARUCOHIP_STOP_AFTER):
+#ifdef ARUCOHIP_STAGE_EXPERIMENT
+    int stop_after = 99;       // stage-cost experiment (tools/stage_cost.sh builds a variant library with this flag and reads ARUCOHIP_STOP_AFTER):
                                // 1 threshold, 2 start candidates, 3 first walker pass, 4 generations, 5 contour_quad, 6 frame_candidates, 7 warp + Otsu, 8 LINES
+#endif
     int threshold_eo = 1;      // ARUCOHIP_THRESHOLD_EO: its round-3 form for 7x7 blocks (unpacked row ring, folded constants); 0 = the round-2 kernel
 };
 Tuning read_tuning();          // capi.hip
+// RUN_STAGE(tune, n): does the pipeline run past stage n? Always, except in the stage-cost experiment's variant build, where the pipeline is cut
+// behind the stage ARUCOHIP_STOP_AFTER names (results are then meaningless; arucohip_build_info() names the flag and bench.py prints no headline).
+#ifdef ARUCOHIP_STAGE_EXPERIMENT
+#define RUN_STAGE(tune, n) ((tune).stop_after > (n))
+#else
+#define RUN_STAGE(tune, n) true
+#endif
 
 // Border lines of a thresholded plane kept beside the bit tiles (lazy byte image): row 0 at 0, row H-1 at Wp, column 0 at 2 Wp, column W-1
 // at 2 Wp + Hp, with Wp / Hp = width / height rounded up to 16 so that every line starts 16-byte aligned (the kernels store 16 and 4 bytes

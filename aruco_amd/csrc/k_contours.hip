@@ -543,14 +543,6 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
     uint32_t base1 = tb_base1(blk), lp = pos - base1, s1c = tb_s1c(s);
     uint32_t p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
     const uint32_t* rb = rows + lane - LANES;
-#ifdef WALK_CLOCK   // debug build only: where a wave's time goes (clock64 ticks), printed by workgroup 0 of every launch
-    long long wc_pre = 0, wc_load = 0, wc_step = 0;
-    int wc_iters = 0, wc_loads = 0, wc_need = 0;
-#define WC(var) do { const long long t_ = clock64(); var += t_ - wc_t; wc_t = t_; } while (0)
-    long long wc_t = clock64();
-#else
-#define WC(var) do { } while (0)
-#endif
     while (__any(walking)) {
         {
             // a side that is clamped to the image needs no margin: the border cannot leave the image
@@ -566,11 +558,6 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 const int ax = abs(x - (int)(pos0 & 0xFFFFu)), ay = abs(y - (int)(pos0 >> 16));
                 if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, was_bad = true;
             }
-            WC(wc_pre);
-#ifdef WALK_CLOCK
-            wc_iters++;
-            if (__any(walking && near)) wc_loads++, wc_need += __popcll(__ballot(walking && near));
-#endif
             if (PER_LANE_RELOAD ? (walking && near) : __any(walking && near)) {
                 if (TB_DIRECTED)
                     tb_load_dir<LANES, CHUNK>(tiles, tnx, tny, at, tb_s_of(s1c), rows, lane, blk);
@@ -579,7 +566,6 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 base1 = tb_base1(blk), lp = at - base1;
                 p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
             }
-            WC(wc_load);
         }
 #pragma unroll
         for (int j = 0; j < CHUNK; j++) {
@@ -618,14 +604,7 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 lp = nlp, s1c = ns1c;   // also when the walk has ended: position and direction only matter to a walk that goes on (WR_LIMIT)
             }
         }
-        WC(wc_step);
     }
-#ifdef WALK_CLOCK
-    WC(wc_step);
-    if (blockIdx.x == 0 && lane == 0)
-        printf("WALK_CLOCK hole %d lim %u: iterations %d with a load %d lanes loading %d | ticks edge tests %lld loads %lld steps %lld\n", (int)HOLE, lim, wc_iters, wc_loads,
-               wc_need, wc_pre, wc_load, wc_step);
-#endif
     const int res = was_bad ? WR_BAD : was_closed ? WR_CLOSED : WR_LIMIT;
     pos = lp + base1, s = tb_s_of(s1c);
     return res;
@@ -869,7 +848,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     int done = a.leash;
     bool forked = false;
     hipStream_t cur = s;
-    for (int g = 1; g <= GEN_MAX && done < p.max_contour && b.tune.stop_after > 3; g++) {   // stop_after: stage-cost experiment only (internal.h)
+    for (int g = 1; g <= GEN_MAX && done < p.max_contour && RUN_STAGE(b.tune, 3); g++) {
         if (g == kForkAfter + 1 && fk.side) {
             hipLaunchKernelGGL(snapshot_kernel, dim3((nplanes + 255) / 256), dim3(256), 0, s, b.trig_cnt, nplanes);
             (void)hipEventRecord(fk.forked, s);

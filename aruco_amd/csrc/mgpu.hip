@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -81,6 +82,8 @@ struct arucohip_mgpu {
     };
     std::vector<Pending> pend;       // per lane
     int next_ticket = 0;
+    bool broken = false;             // a rebuild of the lanes failed and the previous depth could not be restored: every call reports it
+    bool peer_fallback = false;      // ARUCOHIP_MGPU_GATHER_PEER was asked for but a device cannot reach the first one: host gather in use
     std::mutex mu;                   // completion records of all slots
     std::condition_variable cv;
     std::string err;
@@ -202,17 +205,54 @@ void free_staging(arucohip_mgpu* m) {
     m->g_out.clear(), m->g_n.clear(), m->hg_out.clear(), m->hg_n.clear();
 }
 
-// (re)build the lanes: handles' pipelines, staging per lane, workers
-int build_lanes(arucohip_mgpu* m, int depth) {
+// Fault injection for the tests of the two recovery paths below (tests/test_gpu_boundary.py): ARUCOHIP_MGPU_INJECT = "fail_depth:3,1"
+// makes every build of 3 or 1 lanes fail behind its first slot, "nopeer" makes hipDeviceCanAccessPeer read as false. Read per call.
+bool inject_fail_depth(int depth) {
+    const char* e = getenv("ARUCOHIP_MGPU_INJECT");
+    const char* q = e ? strstr(e, "fail_depth:") : nullptr;
+    if (!q) return false;
+    for (q += 11; *q;) {
+        if (atoi(q) == depth) return true;
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+    }
+    return false;
+}
+bool inject_nopeer() {
+    const char* e = getenv("ARUCOHIP_MGPU_INJECT");
+    return e && strstr(e, "nopeer");
+}
+
+// can every device slot write into the first device's memory (xGMI peer access)? Slots on the first device itself need nothing.
+bool peers_reachable(arucohip_mgpu* m) {
+    if (inject_nopeer()) return false;
+    for (size_t g = 1; g < m->slots.size(); g++) {
+        if (m->slots[g]->device == m->slots[0]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, m->slots[g]->device, m->slots[0]->device) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+
+// one attempt to (re)build the lanes: handles' pipelines, staging per lane, workers. On failure nothing runs (the workers start last) but the
+// staging may be partly allocated: build_lanes cleans up.
+int build_lanes_once(arucohip_mgpu* m, int depth) {
     stop_workers(m);
     free_staging(m);
     const int G = (int)m->slots.size();
     const size_t blk = (size_t)m->per_device * m->cap;
+    // the peer gather needs every device to reach the first one; where one cannot, the blocks go through pinned host memory instead
+    if ((m->flags & ARUCOHIP_MGPU_GATHER_PEER) && !peers_reachable(m)) m->flags &= ~ARUCOHIP_MGPU_GATHER_PEER, m->peer_fallback = true;
     const bool peer = (m->flags & ARUCOHIP_MGPU_GATHER_PEER) != 0;
     m->depth = depth;
     m->pend.assign(depth, arucohip_mgpu::Pending());
+    int nslot = 0;
     for (Slot* s : m->slots) {
         MGCHK(m, hipSetDevice(s->device));
+        if (nslot++ == 1 % G && inject_fail_depth(depth)) return mg_fail(m, ARUCOHIP_E_HIP, "injected failure while building the lanes");
         int rc = arucohip_set_pipeline_depth(s->h, depth);
         if (rc) return mg_fail(m, rc, arucohip_last_error_string(s->h));
         s->h_out.assign(depth, nullptr), s->h_n.assign(depth, nullptr), s->d_out.assign(depth, nullptr), s->d_n.assign(depth, nullptr);
@@ -236,13 +276,11 @@ int build_lanes(arucohip_mgpu* m, int depth) {
             MGCHK(m, hipHostMalloc((void**)&m->hg_out[l], (size_t)G * blk * sizeof(arucohip_marker_t)));
             MGCHK(m, hipHostMalloc((void**)&m->hg_n[l], (size_t)G * m->per_device * sizeof(int32_t)));
         }
-        // the writing device needs direct access to the first device's memory for the copy to travel over xGMI; without it
-        // hipMemcpyPeerAsync still works (staged by the runtime), so this is best effort
+        // the writing device maps the first device's memory so that the copy travels over xGMI (peers_reachable has checked that it can;
+        // "already enabled" is not an error)
         for (int g = 1; g < G; g++) {
             if (m->slots[g]->device == m->slots[0]->device) continue;
-            int can = 0;
-            if (hipSetDevice(m->slots[g]->device) == hipSuccess && hipDeviceCanAccessPeer(&can, m->slots[g]->device, m->slots[0]->device) == hipSuccess && can)
-                (void)hipDeviceEnablePeerAccess(m->slots[0]->device, 0);
+            if (hipSetDevice(m->slots[g]->device) == hipSuccess) (void)hipDeviceEnablePeerAccess(m->slots[0]->device, 0);
             (void)hipGetLastError();
         }
     }
@@ -251,6 +289,33 @@ int build_lanes(arucohip_mgpu* m, int depth) {
         m->slots[g]->worker = std::thread(worker_main, m, g);
     }
     return ARUCOHIP_OK;
+}
+
+// Transactional: either the detector runs at `depth` afterwards, or — when that build fails, e.g. out of device memory for the lanes — at the
+// depth it had before, and the call reports the failure. Only when the previous depth cannot be restored either is the detector marked
+// broken: every later submit / wait / detect then returns ARUCOHIP_E_HIP at once instead of queueing work that no thread would take.
+int build_lanes(arucohip_mgpu* m, int depth, int previous) {
+    int rc = build_lanes_once(m, depth);
+    if (rc == ARUCOHIP_OK) {
+        m->broken = false;
+        return rc;
+    }
+    const std::string why = m->err;
+    if (previous > 0 && previous != depth && build_lanes_once(m, previous) == ARUCOHIP_OK) {
+        m->broken = false;
+        m->err = why + " (the previous depth " + std::to_string(previous) + " was restored)";
+        return rc;
+    }
+    stop_workers(m);
+    free_staging(m);
+    for (Slot* s : m->slots) {
+        (void)hipSetDevice(s->device);
+        (void)arucohip_set_pipeline_depth(s->h, 0);
+    }
+    m->depth = 1, m->pend.assign(1, arucohip_mgpu::Pending());
+    m->broken = true;
+    m->err = why + " (no lanes could be built: the detector is unusable, destroy it)";
+    return rc;
 }
 
 }  // namespace
@@ -303,7 +368,7 @@ int arucohip_mgpu_create(const arucohip_params_t* params, const int* devices, in
             return rc;
         }
     }
-    int rc = build_lanes(m, 1);
+    int rc = build_lanes(m, 1, 0);
     if (rc != ARUCOHIP_OK) {
         arucohip_mgpu_destroy(m);
         return rc;
@@ -332,9 +397,11 @@ int arucohip_mgpu_set_depth(arucohip_mgpu* m, int depth) {
     if (!m || depth < 1 || depth > 8) return ARUCOHIP_E_INVALID;
     for (auto& pd : m->pend)
         if (pd.active) return mg_fail(m, ARUCOHIP_E_INVALID, "a submitted batch has not been waited for");
-    if (depth == m->depth) return ARUCOHIP_OK;
-    return build_lanes(m, depth);
+    if (depth == m->depth && !m->broken) return ARUCOHIP_OK;
+    return build_lanes(m, depth, m->broken ? 0 : m->depth);
 }
+
+int arucohip_mgpu_gather_mode(const arucohip_mgpu* m) { return (m && (m->flags & ARUCOHIP_MGPU_GATHER_PEER)) ? ARUCOHIP_MGPU_GATHER_PEER : ARUCOHIP_MGPU_GATHER_HOST; }
 
 }  // extern "C"
 
@@ -344,6 +411,7 @@ int submit_common(arucohip_mgpu* m, int kind, const std::vector<const uint8_t*>&
                   size_t fstride, const float* K, const float* dist, int ndist, float marker_size, int y_perp, arucohip_marker_t* out, int cap, int32_t* n_out,
                   int* ticket) {
     if (ndist < 0 || ndist > 8) return mg_fail(m, ARUCOHIP_E_INVALID, "ndist must be 0..8");
+    if (m->broken) return mg_fail(m, ARUCOHIP_E_HIP, "the detector has no lanes (an earlier arucohip_mgpu_set_depth failed and could not be rolled back)");
     const int lane = m->next_ticket % m->depth;
     if (m->pend[lane].active) return mg_fail(m, ARUCOHIP_E_CAPACITY, "pipeline full: wait for the oldest ticket first");
     auto& pd = m->pend[lane];
@@ -404,6 +472,7 @@ int arucohip_mgpu_submit_streams(arucohip_mgpu* m, const uint8_t* const* frames_
 
 int arucohip_mgpu_wait(arucohip_mgpu* m, int ticket) {
     if (!m || ticket < 0) return ARUCOHIP_E_INVALID;
+    if (m->broken) return mg_fail(m, ARUCOHIP_E_HIP, "the detector has no lanes (an earlier arucohip_mgpu_set_depth failed and could not be rolled back)");
     const int lane = ticket % m->depth;
     auto& pd = m->pend[lane];
     if (!pd.active || pd.ticket != ticket) return mg_fail(m, ARUCOHIP_E_INVALID, "no such batch in flight");

@@ -135,11 +135,11 @@ class GatherPipeline:
     valid until the slot's next submit), elsewhere None.
     The collective runs on a process group of its own, so it never queues behind (or in front of) the caller's barriers and reductions."""
 
-    def __init__(self, nframes, cap, cap_total, depth, device, dst=0, new_group=True, always_collective=False):
+    def __init__(self, nframes, cap, cap_total, depth, device, dst=0, new_group=True, always_collective=False, to_host=False):
         self.nframes, self.cap, self.cap_total, self.depth, self.dst = nframes, cap, cap_total, depth, dst
         self.device = torch.device(device)
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
         # always_collective: issue the gather also in a world of one rank (the single-GPU test of the RCCL code path)
         self.collective = self.world > 1 or always_collective
         self.group = dist.new_group() if (new_group and self.collective) else None
@@ -151,9 +151,14 @@ class GatherPipeline:
         self.work = [None] * depth
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.bytes_per_step = nbytes
+        # to_host (one rank, no collective): the packed block of every batch is also copied to pinned host memory on this object's stream -
+        # what a single-GPU consumer of the results pays per batch; wait(slot) then returns the host block
+        self.to_host = bool(to_host) and self.on_gpu and not self.collective
+        self.host = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(depth)] if self.to_host else None
+        self.host_ev = [None] * depth
 
     def submit(self, slot, markers_u8, counts_i32):
-        if self.work[slot] is not None:
+        if self.work[slot] is not None or self.host_ev[slot] is not None:
             self.wait(slot)
         ev = None
         if self.on_gpu:
@@ -165,6 +170,10 @@ class GatherPipeline:
                 ev.record(self.stream)
                 if self.collective:
                     self.work[slot] = dist.gather(self.send[slot], self.recv[slot], dst=self.dst, group=self.group, async_op=True)
+                elif self.to_host:
+                    self.host[slot].copy_(self.send[slot], non_blocking=True)       # D2H behind the packing kernel, on this object's stream
+                    self.host_ev[slot] = torch.cuda.Event()
+                    self.host_ev[slot].record(self.stream)
         else:
             self.send[slot].copy_(pack_block(markers_u8, counts_i32, self.cap, self.cap_total))
             if self.collective:
@@ -177,9 +186,18 @@ class GatherPipeline:
             if self.on_gpu:
                 with torch.cuda.stream(self.stream):
                     w.wait()          # this object's stream waits for RCCL; the detector's stream is not involved
+                # ... and the CONSUMER is ordered behind it: for RCCL w.wait() only makes self.stream wait, the host does not block. Whoever reads
+                # the returned blocks does so on torch's current stream (unpack_block's .cpu() is a copy on it, and the host waits for that
+                # copy), so that stream now waits for this object's stream and therefore for the gather.
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
             else:
                 w.wait()
             self.work[slot] = None
+        if self.to_host:
+            if self.host_ev[slot] is not None:
+                self.host_ev[slot].synchronize()      # the host blocks until the copy of that batch's block has landed
+                self.host_ev[slot] = None
+            return [self.host[slot]]
         if not self.collective:
             return [self.send[slot]]
         return self.recv[slot] if self.rank == self.dst else None

@@ -35,9 +35,77 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-ALG_BYTES_PER_FRAME = 3 * W * H          # gray read + threshold write + threshold read
+ALG_BYTES_PER_FRAME = 3 * W * H          # SURVEY.md §8d's recipe: gray read + byte-image write + byte-image read (whole-pipeline figure)
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CAP = 64                                 # marker slots per frame in the gathered block (config 5)
+
+
+def threshold_own_bytes(w, h):
+    """ALGORITHMIC bytes per frame of the streaming kernel (threshold_eo_kernel) as it is built since round 2: it reads the gray frame once
+    and writes the thresholded image as bits - the 8x8-pixel tiles (one zero pad tile row / column, aruco_amd/csrc/bits_tiles.h), the
+    non-empty-tile bitmap (two words per 128-tile strip and tile row) and the four border lines of the lazy byte image (each padded to 16
+    bytes, internal.h: thres_edge_stride). Nobody reads W*H back: the contour kernels read the tiles. 1080p: 2 073 600 + 262 208 + 4 352 +
+    6 016 = 2 346 176 B = 1.131 W*H (SURVEY 8d's recipe charges 3 W*H, a byte image written and read again, which this pipeline replaced)."""
+    tx, ty = max((w + 7) // 8 + 1, 4), max((h + 7) // 8 + 1, 4)
+    strips = (w + 1023) // 1024
+    return w * h + tx * ty * 8 + ty * 2 * strips * 8 + 2 * ((w + 15) & ~15) + 2 * ((h + 15) & ~15)
+
+
+def h2d_ceiling_gbps(torch, dev, nbytes=1 << 30, reps=4):
+    """Plain pinned-host -> device hipMemcpyAsync rate of THIS box (one stream, 1 GiB per copy): the ceiling the --host-frames leg is
+    compared with."""
+    src = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        dst.copy_(src, non_blocking=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        e1.record(st)
+    e1.synchronize()
+    return reps * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def thread_scaling_leg(capi, frame_1080p, threads=(1, 4, 16), seconds=1.5):
+    """The reference's call shape under load: T host threads, each with a detector of its own (MarkerDetector is not re-entrant, one object
+    per thread: src/markerdetector.cpp:334,372-380), each calling detect() on one pinned 1080p host frame per call in a loop
+    (utils/aruco_test.cpp:153-160's frame loop, T cameras). frames/s over all threads; ctypes releases the GIL during the call."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    out = {}
+    for T in threads:
+        pinned = [torch.empty(frame_1080p.shape, dtype=torch.uint8, pin_memory=True) for _ in range(T)]
+        for p in pinned:
+            p.copy_(torch.from_numpy(np.ascontiguousarray(frame_1080p)))
+        frames = [p.numpy() for p in pinned]
+        hs = [capi.Handle(frame_1080p.shape[1], frame_1080p.shape[0], max_batch=1) for _ in range(T)]
+        counts, stop = [0] * T, threading.Event()
+        try:
+            for i in range(T):
+                hs[i].detect(frames[i])
+
+            def work(i):
+                while not stop.is_set():
+                    hs[i].detect(frames[i])
+                    counts[i] += 1
+            th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            time.sleep(seconds)
+            stop.set()
+            for t in th:
+                t.join()
+            out[str(T)] = round(sum(counts) / (time.perf_counter() - t0), 1)
+        finally:
+            for h in hs:
+                h.close()
+    return out
 
 
 def cpu_baseline(frames_host, seconds_single=8.0, seconds_multi=12.0):
@@ -214,6 +282,8 @@ def stub_main(args, rank, world):
     blocks["id"][:, 0] = rank
     mt = torch.from_numpy(blocks.view(np.uint8).reshape(B, CAP * 96).copy())
     ct = torch.ones(B, dtype=torch.int32)
+    valid = B if (rank < world - 1 or world == 1) else B - B // 3      # ragged last shard: the last rank's stream ends early (padding frames, count 0)
+    ct[valid:] = 0
     cap_total = adist.agree_capacity(int(ct.sum()), B, CAP, torch.device("cpu")) if world > 1 else B * CAP
     gp = adist.GatherPipeline(B, CAP, cap_total, depth, "cpu") if world > 1 else None
     last = None
@@ -239,13 +309,15 @@ def stub_main(args, rank, world):
         dist.barrier()
     elapsed = adist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
     if rank == 0:
-        ranks_seen = [0]
+        ranks_seen, frames_seen = [0], valid
         if last is not None:
-            ranks_seen = sorted(int(adist.unpack_block(blk, CAP, MARKER_DTYPE)[1][0][0]["id"]) for blk in last)
+            un = [adist.unpack_block(blk, CAP, MARKER_DTYPE) for blk in last]
+            ranks_seen = sorted(int(u[1][0][0]["id"]) for u in un)
+            frames_seen = sum(int((u[0] > 0).sum()) for u in un)
         print(json.dumps({"metric": "frames/sec at %d×%d" % (W, H), "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-                          "data": "stub (launcher test, no GPU work)", "config": {"workload": "stub", "ranks_gathered": ranks_seen,
+                          "data": "stub (launcher test, no GPU work)", "config": {"workload": "stub", "ranks_gathered": ranks_seen, "frames_gathered": frames_seen, "frames_per_rank": B,
                                                                                  "gather_bytes_per_rank_and_step": gp.bytes_per_step if gp else 0}}), flush=True)
     if world > 1:
         dist.barrier()
@@ -288,11 +360,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (extra keys of the JSON line)")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of configs 3 / 4 / pinned H2D / clutter (extra key other_configs)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 (tools/profile.sh): warm-up + timed steps at the default depth only - no instrumented / isolated passes, no legs - "
+                         "so that EVERY dispatch in the trace is an in-stream launch of the configuration the headline is measured on")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher test on CPU (gloo), see stub_main
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", default_hw_queues(args.config))   # before torch / HIP start; the launched ranks inherit it
 
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not args.stub:
+        # fail before any GPU call, with a message, when the node has fewer devices than ranks were asked for (counting devices does not
+        # initialise the HIP runtime on this image)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); nothing was run\n" % (args.gpus, have))
+            sys.exit(2)
     if args.gpus > 1 and not in_rank:
         sys.exit(launch_ranks(args.gpus))     # before torch / HIP are touched in this process
     if args.stub:
@@ -317,6 +400,8 @@ def main():
     from aruco_amd import dist as adist
 
     capi.load()
+    build = capi.build_info()
+    experiment = "ARUCOHIP_STAGE_EXPERIMENT" in build
     if args.config == 3:
         args.pose = True
     global W, H, ALG_BYTES_PER_FRAME
@@ -370,9 +455,11 @@ def main():
     def src_of(off):
         return frames_host[off].data_ptr() if frames_host is not None else frames[off].data_ptr()   # host frames: H2D is part of the step
 
-    # ---- N > 1: the capacity of the packed gather block, agreed once between the ranks from one pass over every window of the stream
+    # ---- the capacity of the packed result block from one pass over every window of the stream (N > 1: agreed between the ranks). The block
+    # is what leaves the GPU every step: at N > 1 it is gathered to rank 0 over RCCL, at N = 1 it is copied to pinned host memory - both
+    # asynchronously on the pipeline's own stream, waited for `depth` steps later, INSIDE the timed region (a consumer pays for it).
     gp, cap_total = None, B * CAP
-    if world > 1:
+    if not experiment:
         most = 0
         for w in range(nwin):
             if frames_host is not None:
@@ -382,7 +469,7 @@ def main():
             handle.batch_status()
             most = max(most, int(cnt.clamp(0, CAP).sum().item()))
         cap_total = adist.agree_capacity(most, B, CAP, dev)
-        gp = adist.GatherPipeline(B, CAP, cap_total, depth, dev)
+        gp = adist.GatherPipeline(B, CAP, cap_total, depth, dev, to_host=(world == 1))
     if depth > 1:
         handle.set_pipeline_depth(depth)      # `depth` complete workers: batch i+1's threshold runs under batch i's border following
     tickets = [None] * depth
@@ -450,10 +537,11 @@ def main():
     elapsed = adist.max_over_ranks(elapsed, dev)
 
     # ---- correctness guard, right behind the timed region and on ITS last batch: the detected ids are rendered ids
-    if os.environ.get("ARUCOHIP_STOP_AFTER"):
-        # tools/stage_cost.sh: a library built for the stage-cost experiment runs a truncated pipeline; only the step time means anything
-        print(json.dumps({"experiment": "stage_cost", "stop_after": int(os.environ["ARUCOHIP_STOP_AFTER"]), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-                          "invalid": "truncated pipeline, no results"}))
+    if experiment:
+        # tools/stage_cost.sh: a variant built with -DARUCOHIP_STAGE_EXPERIMENT runs a truncated pipeline; only the step time means anything.
+        # arucohip_build_info() of the loaded library says so - such a build never gets a headline line, whatever the environment says.
+        print(json.dumps({"experiment": "stage_cost", "build": build, "stop_after": int(os.environ.get("ARUCOHIP_STOP_AFTER", "99")),
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "invalid": "truncated pipeline, no results"}))
         return
     gslot = last["slot"]
     n_host = cnts[gslot].cpu().numpy()
@@ -471,8 +559,16 @@ def main():
         raise SystemExit("only %d of %d rendered markers detected" % (found, rendered))
     if board is not None and sum(b["has_pose"] for b in boards) < 0.95 * B:
         raise SystemExit("board pose missing on some frames")
+    if gp is not None and world == 1:
+        # N = 1: what arrived in pinned host memory for that batch equals its device result arrays
+        c, fr, ovf = adist.unpack_block(gp.wait(gslot)[0], CAP, capi.MARKER_DTYPE)
+        if ovf:
+            raise SystemExit("the packed result block overflowed its capacity (%d markers)" % cap_total)
+        for f in range(B):
+            if fr[f] is None or fr[f].tobytes() != arr[f, :min(max(n_host[f], 0), CAP)].tobytes():
+                raise SystemExit("host copy of the packed results differs from the device arrays at frame %d" % f)
     gathered = None
-    if gp is not None and rank == 0:
+    if gp is not None and rank == 0 and world > 1:
         # what arrived on rank 0 for that batch: every rank's packed block, none overflowed, rank 0's own equals its result arrays
         gathered = gp.wait(gslot)
         tot = 0
@@ -488,6 +584,15 @@ def main():
         if tot < 0.9 * rendered * world:
             raise SystemExit("gathered markers: %d of about %d" % (tot, rendered * world))
 
+    if args.profile_run:
+        if rank == 0:
+            print(json.dumps({"profile_run": True, "build": build, "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s", "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "batches_in_flight": depth, "frames_per_launch": B,
+                              "note": "every dispatch of this process is an in-stream launch at the bench's default depth (no instrumented passes)"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- instrumented passes, outside the timed region: per-kernel hipEvent intervals and the threshold kernel's device-clock span with
     # the same batches in flight, then one batch at a time (what rocprofv3 shows per dispatch when nothing else runs)
     gp_keep, gp = gp, None                      # the instrumented passes do not gather
@@ -516,34 +621,56 @@ def main():
     if rank == 0:
         total_frames = world * B * args.steps
         fps = total_frames / elapsed
-        # The roofline object is about the pipeline's one HBM-streaming kernel, the adaptive threshold pass: SURVEY §8d's algorithmic bytes
-        # (3 W H per frame) are that pass's traffic model. Since round 3 it is no longer the longest kernel of a batch — the border
-        # walkers are, a chain of dependent steps for which no byte figure exists; `longest_kernel` names it.
+        # The roofline object is about the pipeline's one HBM-streaming kernel, the adaptive threshold pass. `achieved` / `frac` price it in
+        # ITS OWN algorithmic bytes (threshold_own_bytes: gray read + bit tiles + bitmap + border lines written) over the duration of its
+        # launches IN THE STREAM (batches in flight); SURVEY 8d's 3 W H recipe is kept as frac_survey_recipe, with the reason it can
+        # exceed 1. The longest kernel of a batch is the border walk, a chain of dependent steps without a byte figure (`longest_kernel`).
         dom = "threshold_kernel"
         longest = max(ktimes_iso, key=lambda k: ktimes_iso[k])
-        # Duration of its launches with the batches in flight: the device-clock span of each launch (what rocprofv3 reports per
-        # dispatch); its hipEvent interval is also printed (event_interval_ms): that one contains the time the dispatch queues behind the
-        # other batches' kernels.
+        own = threshold_own_bytes(W, H)
+        # in-stream duration: the device-clock span of each launch of the instrumented pass (first wave in to last wave out - what rocprofv3
+        # reports per dispatch; tools/profile.sh --profile-run gives the same from the trace alone). The hipEvent interval (event_interval_ms)
+        # also contains the time the dispatch queues behind the other batches' kernels.
         dom_ms = ktimes[dom]
         event_ms = dom_ms
         if exec_n > 0:
             dom_ms = exec_ms / exec_n
-        achieved = ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes of that kernel: FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes of this command, committed under
-        # profiles/ (separate passes, tools/profile.sh) — a replay of that measurement scaled to this launch, not a live counter
-        traffic, traffic_src, pipe_traffic = None, None, None
+        achieved = own * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        iso_ms = ktimes_iso.get(dom, dom_ms)
+        # HBM bytes per launch: FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes of THIS build at THIS depth (separate passes,
+        # tools/profile.sh -> profiles/hbm_traffic.json), replayed - only when the file's build digest equals the loaded library's and the
+        # passes were made at the depth this run uses; otherwise traffic is null and traffic_source says why (no stale replay).
+        traffic, traffic_src, pipe_traffic, others = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.config in (2, 3) and not args.clutter:     # the committed PMC passes are of the 1080p stream
+        if not os.path.exists(tpath):
+            traffic_src = "no profiles/hbm_traffic.json"
+        elif args.config not in (2, 3) or args.clutter or args.host_frames:
+            traffic_src = "the committed PMC passes are of the default 1080p stream, not of this configuration"
+        else:
             try:
                 tj = json.load(open(tpath))
-                if dom in tj.get("kernels", {}):
-                    traffic = tj["kernels"][dom]["hbm_bytes_per_frame"] * per_launch
-                    traffic_src = "profiles/hbm_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, replayed" % tj.get("tag", "")
-                if args.config == 2:   # all kernels of a batch (the passes are of config 2)
-                    pipe_traffic = sum(k["hbm_bytes_per_frame"] for k in tj["kernels"].values()) * B
-            except Exception:
-                traffic = None
-        iso_ms = ktimes_iso.get(dom, dom_ms)
+                if tj.get("build") != build:
+                    traffic_src = "stale: profiles/hbm_traffic.json (%s) is of build '%s', the loaded library is '%s' - rerun tools/profile.sh" % (tj.get("tag", ""), tj.get("build"), build)
+                elif tj.get("batches_in_flight") not in (None, depth):
+                    traffic_src = "profiles/hbm_traffic.json (%s) was collected with %s batches in flight, this run uses %d" % (tj.get("tag", ""), tj.get("batches_in_flight"), depth)
+                else:
+                    kk = tj["kernels"]
+                    traffic = kk[dom]["hbm_bytes_per_frame"] * per_launch
+                    traffic_src = ("profiles/hbm_traffic.json (%s, same build, %s batches in flight): rocprofv3 --pmc FETCH_SIZE (x2 for this kernel's 16-byte-per-lane "
+                                   "reads, MI355X_MICROARCH.md) + WRITE_SIZE, separate passes, replayed per launch" % (tj.get("tag", ""), tj.get("batches_in_flight")))
+                    if args.config == 2:   # all kernels of a batch (the passes are of config 2)
+                        pipe_traffic = sum(k["hbm_bytes_per_frame"] for k in kk.values()) * B
+                        # traffic / algorithmic bytes of the three gather-type kernels (per frame): what each re-reads
+                        tiles_b = max((W + 7) // 8 + 1, 4) * max((H + 7) // 8 + 1, 4) * 8
+                        fillc = handle.debug_counters()
+                        npts = fillc["points"] / max(B, 1)
+                        alg = {"walker_long_kernel": (tiles_b, "the frame's bit-tile array once"),
+                               "warp_hist_kernel": (48 * 56 * 56, "48 candidates x 56 x 56 nearest-neighbour samples"),
+                               "contour_quad_kernel": (npts * 4 + tiles_b * 0.35, "4 B per kept contour point written + the tiles under the kept borders (~35 %% of the array)")}
+                        others = {k: {"traffic_bytes_per_frame": round(kk[k]["hbm_bytes_per_frame"]), "algorithmic_bytes_per_frame": round(v[0]),
+                                      "traffic_over_algorithmic": round(kk[k]["hbm_bytes_per_frame"] / v[0], 2), "algorithmic": v[1]} for k, v in alg.items() if k in kk}
+            except Exception as e:   # a malformed file is reported, not replayed
+                traffic, traffic_src = None, "profiles/hbm_traffic.json unreadable: %r" % (e,)
         res = {
             "metric": "frames/sec at %d×%d" % (W, H), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -552,39 +679,56 @@ def main():
                                     "1920x1080 synthetic stream, ~20 markers/frame, threshold+contour+decode+LINES"
                                     + (" + per-marker solvePnP (config 3)" if args.pose else ", no pose (config 2)"))
                                    + (", frames start in pinned host memory (PCIe inclusive)" if args.host_frames else "")
-                                   + (", textured backgrounds (robustness leg, not the headline)" if args.clutter else ""),
+                                   + (", textured backgrounds (second headline: what camera frames look like)" if args.clutter else ""),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": args.frames, "markers_rendered_per_frame": 24 if board is not None else 20,
-                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth,
-                       "timed_region": "no per-kernel instrumentation; kernel times and the device-clock span come from separate passes after it",
+                       "markers_detected_per_frame": round(found / B, 2), "batches_in_flight": depth, "build": build,
+                       "timed_region": "no per-kernel instrumentation; every batch's packed result block (%d bytes) leaves the GPU inside it, asynchronously: "
+                                       % (gp_keep.bytes_per_step if gp_keep is not None else 0)
+                                       + ("copied to pinned host memory" if world == 1 else "gathered to rank 0 over RCCL") + ", waited for `batches_in_flight` steps later",
                        "thresholded_image": "written in the hot path" if os.environ.get("ARUCOHIP_THRES_BYTES", "0") not in ("", "0") else
                        "kept as bit tiles + border lines, bytes on request (ARUCOHIP_THRES_BYTES=1 writes them in the hot path)", "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "frames sharded 1 stream/GPU"
                        + (", packed marker blocks gathered over RCCL per step, asynchronously (own stream and process group), %d bytes per rank" % gp_keep.bytes_per_step
-                          if gp_keep is not None else "")},
+                          if (gp_keep is not None and world > 1) else "")},
             "hbm_algorithmic_gbps": round(ALG_BYTES_PER_FRAME * fps / 1e9, 2),
             "hbm_frac_of_peak": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
-            # frac: SURVEY §8d recipe (3 W H bytes per frame) over the kernel's execution span with the batches in flight (instrumented pass).
-            # frac_isolated: the same over the kernel's duration when one batch runs alone. frac_own_bytes: the bytes the kernel itself
-            # moves (PMC) over that isolated duration. frac_pipeline: algorithmic bytes of all frames over the whole timed step.
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * per_launch, "frames_per_launch": per_launch,
-                         "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4),
-                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the instrumented pass (%d batches in flight)" % (exec_n, depth)
+                         "algorithmic_bytes_per_launch": own * per_launch, "algorithmic_bytes_per_frame": own,
+                         "algorithmic_bytes_formula": "W*H gray read + tiles_x*tiles_y*8 bit tiles + tiles_y*2*strips*8 bitmap + 2*Wp + 2*Hp border lines written "
+                                                      "(bench.py: threshold_own_bytes; DESIGN.md 5)",
+                         "frames_per_launch": per_launch, "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4),
+                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the instrumented pass (%d batches in flight); "
+                                                 "profiles/: rocprofv3 average of the same kernel under bench.py --profile-run" % (exec_n, depth)
                          if exec_n > 0 else "hipEvent interval on the launch stream",
-                         "event_interval_ms": round(event_ms, 4), "frac_event_interval": round(ALG_BYTES_PER_FRAME * per_launch / (event_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if event_ms > 0 else None,
+                         "traffic_over_algorithmic": round(traffic / (own * per_launch), 3) if traffic else None,
+                         "frac_traffic": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and dom_ms > 0 else None,
+                         "event_interval_ms": round(event_ms, 4),
                          "isolated_launch_ms": round(iso_ms, 4),
                          "isolated_launch_ms_device_clock": round(iso_exec_ms / iso_exec_n, 4) if iso_exec_n > 0 else None,
-                         "frac_isolated": round(ALG_BYTES_PER_FRAME * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
-                         "frac_own_bytes": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
+                         "frac_isolated": round(own * per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if iso_ms > 0 else None,
+                         "frac_traffic_isolated": round(traffic / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and iso_ms > 0 else None,
+                         # SURVEY 8d's recipe: 3 W H per frame over the same in-stream duration. It charges a W*H byte-image write and a W*H
+                         # byte-image read that this pipeline replaced by a bit image (1/8 of the bytes, written once), so it can exceed 1.
+                         "frac_survey_recipe": round(ALG_BYTES_PER_FRAME * per_launch / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if dom_ms > 0 else None,
+                         "frac_survey_recipe_note": "3*W*H per frame (SURVEY 8d) over avg_launch_ms; exceeds the kernel's real bytes 2.65x because the byte image it charges "
+                                                    "(one write, one read) is kept as bits",
                          "frac_pipeline": round(ALG_BYTES_PER_FRAME * fps / 1e9 / (HBM_PEAK_GBPS * world), 5),
                          # every kernel's PMC bytes (replayed like `traffic`) over the step: how much of the peak the pipeline really moves
                          "pipeline_traffic_per_step": pipe_traffic,
-                         "frac_pipeline_own_bytes": round(pipe_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 5) if pipe_traffic else None,
+                         "frac_pipeline_traffic": round(pipe_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 5) if pipe_traffic else None,
+                         "pipeline_bound": "not HBM: vector-instruction issue and gather latency of the contour stages (DESIGN.md 6c/6d)",
+                         "other_kernels": others,
                          "longest_kernel": longest, "longest_kernel_isolated_ms": round(ktimes_iso[longest], 4),
                          "longest_kernel_note": "a latency-bound chain of dependent border steps; SURVEY 8d defines no algorithmic bytes for it"},
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_isolated": {k: round(v, 4) for k, v in ktimes_iso.items()},
         }
+        if args.host_frames and world == 1:
+            # the link: what this box's plain pinned hipMemcpyAsync reaches, and what the detector's frame copies reach inside the step
+            ceil_gbps = h2d_ceiling_gbps(torch, dev)
+            got_gbps = fps * W * H / 1e9
+            res["h2d"] = {"plain_hipMemcpyAsync_gbps": round(ceil_gbps, 2), "achieved_gbps": round(got_gbps, 2), "frac_of_ceiling": round(got_gbps / ceil_gbps, 4),
+                          "note": "pinned host -> device, 1 GiB copies on one stream, measured in this process after the timed region"}
         if fill is not None:
             res["list_fill_per_frame"] = {k: (round(v / B, 1) if k != "status" else v) for k, v in fill.items()}
         if world == 1 and not args.no_cpu_baseline:
@@ -596,6 +740,9 @@ def main():
             handle.set_pipeline_depth(0) if depth > 1 else None      # free the lanes' memory before the small handles / the child processes
         if world == 1 and not args.no_latency and args.config != 4:
             res["latency"] = latency_leg(capi, frame0)
+            res["latency"]["threads_x_detectors_1080p_fps"] = thread_scaling_leg(capi, frame0)
+            res["latency"]["threads_note"] = ("T host threads, one detector each, one pinned 1080p host frame per detect() call (H2D, kernels, D2H per call): "
+                                              "frames/s over all threads for T = 1, 4, 16")
         if legs:
             # the other configurations of BASELINE.json on the same clock as the headline: short runs, each a child process of its own
             handle.close()
@@ -604,8 +751,8 @@ def main():
             oc = {}
             for key, extra in (("config3_fps", ["--config", "3", "--steps", "20", "--warmup", "5"]),    # like the headline: five batches in flight fill and drain inside the timed steps
                                ("config4_fps", ["--config", "4", "--steps", "30", "--warmup", "6"]),   # 128-frame batches, six in flight: 12 steps are two rounds
-                               ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "6", "--warmup", "2"]),
-                               ("config2_clutter_fps", ["--clutter", "--batch", "256", "--frames", "256", "--steps", "20", "--warmup", "5"])):
+                               ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "8", "--warmup", "3"]),
+                               ("config2_clutter_fps", ["--clutter", "--steps", "20", "--warmup", "5"])):
                 d = run_leg(extra)
                 if "error" in d:
                     oc[key] = None
@@ -617,8 +764,11 @@ def main():
                     if key == "config2_clutter_fps":
                         oc["config2_clutter_list_fill_per_frame"] = d.get("list_fill_per_frame")
                         oc["config2_clutter_kernel_ms_isolated"] = d.get("kernel_ms_isolated")
+                    if key == "config2_pinned_h2d_fps":
+                        oc["config2_pinned_h2d"] = d.get("h2d")
             oc["note"] = ("each a short run of `python bench.py` with the flags of that configuration in a child process (ids-subset guard as the "
-                          "headline); config2_pinned_h2d = frames start in pinned host memory, H2D inside the step; clutter = textured backgrounds, 256-frame batches")
+                          "headline); config2_pinned_h2d = frames start in pinned host memory, H2D inside the step (h2d: the link rate it reaches against this box's plain "
+                          "hipMemcpyAsync ceiling); clutter = the second headline: the same 1024-frame stream with textured backgrounds behind the markers")
             res["other_configs"] = oc
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -101,6 +101,9 @@ typedef struct arucohip_limits {
 typedef struct arucohip_handle arucohip_handle;
 
 int arucohip_version(void);
+/* "src=<digest of the library's sources> flags=[<extra compiler flags of a variant build>]": which build is loaded. An experiment build
+ * (tools/stage_cost.sh: -DARUCOHIP_STAGE_EXPERIMENT truncates the pipeline) says so here, and bench.py refuses to print a headline for it. */
+const char* arucohip_build_info(void);
 void arucohip_default_params(arucohip_params_t* p);
 void arucohip_default_limits(arucohip_limits_t* l, int max_width, int max_height, int max_batch);
 
@@ -340,7 +343,10 @@ int arucohip_mgpu_detect_streams(arucohip_mgpu* m, const uint8_t* const* frames_
  * at once with a ticket; arucohip_mgpu_wait(ticket) blocks until every slot's sub-batch is complete and the gathered blocks are in `out` /
  * `n_out` (same layout as the synchronous calls, which are submit + wait). Frames and output arrays of a ticket stay untouched until
  * its wait returns; tickets are waited for in the order they were submitted. */
-int arucohip_mgpu_set_depth(arucohip_mgpu* m, int depth);
+int arucohip_mgpu_set_depth(arucohip_mgpu* m, int depth);   /* transactional: on failure the previous depth keeps running */
+/* The gather in use: ARUCOHIP_MGPU_GATHER_PEER only if it was asked for AND every device can reach the first one (hipDeviceCanAccessPeer);
+ * otherwise the blocks go through pinned host memory (ARUCOHIP_MGPU_GATHER_HOST). */
+int arucohip_mgpu_gather_mode(const arucohip_mgpu* m);
 int arucohip_mgpu_submit_batch(arucohip_mgpu* m, const uint8_t* frames, int nframes, int width, int height, size_t row_stride,
                                size_t frame_stride, const float* K, const float* dist, int ndist, float marker_size,
                                int y_perpendicular, arucohip_marker_t* out, int cap, int32_t* n_out, int* ticket);

@@ -186,3 +186,43 @@ def test_bench_launches_its_own_ranks():
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["config"]["ranks_gathered"] == [0, 1]
     assert doc["value"] > 0 and doc["data"].startswith("stub")
+
+
+def test_bench_stub_world_8_with_a_ragged_last_shard():
+    """The launcher at the node's full width without a GPU: `python bench.py --gpus 8 --stub` starts eight gloo ranks on 127.0.0.1, every rank
+    runs the overlapped packed gather (GatherPipeline, three in flight), the last rank's stream is ragged (a third of its frames are
+    padding), and rank 0 ends up with one block of every rank and exactly the valid frames."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--stub"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    B = doc["config"]["frames_per_rank"]
+    assert doc["n_gpus"] == 8 and doc["config"]["ranks_gathered"] == list(range(8))
+    assert doc["config"]["frames_gathered"] == 7 * B + (B - B // 3)
+    assert doc["scaling"] == "weak" and doc["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` with fewer than N visible HIP devices: a clear message and a non-zero exit code BEFORE any GPU call or rank is started
+    (this container has no GPU at all; on a one-GPU box the same holds for --gpus 2)."""
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this box really has 8 devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 2
+    assert "--gpus 8 but only" in r.stderr and r.stdout.strip() == ""

@@ -161,3 +161,47 @@ def test_one_cluttered_frame_does_not_void_its_batch(env):
             assert a[f, :c[f]].tobytes() == ref[f].tobytes(), f
     finally:
         small.close()
+
+
+def test_retry_handle_follows_decoder_changes(env):
+    """The cached one-frame handle of arucohip_detect_batch_retry_overflowed must not outlive the decoder it was built with: retry (built-in
+    decoder) -> install a caller's decoder that rejects everything -> retry again: the retried frame now has no markers, like every other
+    frame of the batch; remove the callback -> the markers are back. (Round 3 kept the first retry handle: its frames were decoded with
+    the old decoder.)"""
+    capi, torch = env["capi"], env["torch"]
+    from aruco_amd import synth
+    frames, _ = synth.make_stream(4, width=1920, height=1080, seed=79, device="cuda")
+    clut, _ = synth.make_stream(1, width=1920, height=1080, seed=5, device="cuda", clutter=True)
+    fr = frames.cpu().numpy().copy()
+    fr[2] = clut[0].cpu().numpy()
+    big = capi.Handle(1920, 1080, max_batch=4)
+    try:
+        ref = big.detect_batch_host(fr, cap=64)
+    finally:
+        big.close()
+    assert len(ref[2]) >= 10
+    lim = capi.Limits()
+    capi.load().arucohip_default_limits(C.byref(lim), 1920, 1080, 4)
+    lim.long_walks_per_plane = 64
+    lim.contours_per_frame = 128            # the textured frame keeps more borders than that, the flat ones about a hundred
+    small = capi.Handle(1920, 1080, max_batch=4, limits=lim)
+    try:
+        got, retried, first = small.detect_batch_host_tolerant(fr, cap=64)
+        assert first[2] < 0 and retried >= 1
+        for f in range(4):
+            assert got[f] is not None and (f != 2 or got[f].tobytes() == ref[f].tobytes())
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int))
+        fn = FN(lambda user, patch, size, nrot: -1)
+        L = capi.load()
+        assert L.arucohip_set_decoder_callback(small.h, C.cast(fn, C.c_void_p), None) == 0
+        p = small.get_params()
+        p.decoder_kind = 2
+        small.set_params(p)
+        got, retried, first = small.detect_batch_host_tolerant(fr, cap=64)
+        assert first[2] < 0 and retried >= 1
+        assert all(g is not None and len(g) == 0 for g in got)
+        assert L.arucohip_set_decoder_callback(small.h, None, None) == 0
+        got, retried, _ = small.detect_batch_host_tolerant(fr, cap=64)
+        assert got[2].tobytes() == ref[2].tobytes()
+    finally:
+        small.close()

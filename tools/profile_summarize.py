@@ -6,6 +6,18 @@ import csv, json, os, sys, collections
 tag = sys.argv[1]
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 src = os.path.join("gpurun_out", "prof_" + tag)
+# the profiled command's own line (bench.py --profile-run): which build, how many batches in flight, frames per launch
+run = {}
+for log in ("fetch.log", "trace.log"):
+    try:
+        for line in open(os.path.join(src, log)):
+            if line.startswith('{"profile_run"'):
+                run = json.loads(line)
+    except OSError:
+        pass
+    if run:
+        break
+frames = run.get("frames_per_launch", frames)
 os.makedirs("profiles", exist_ok=True)
 rows = list(csv.reader(open(os.path.join(src, "kernel_stats.csv"))))
 rows = [rows[0]] + [r for r in rows[1:] if "ah::" in r[0]]   # this library's kernels only (torch's frame generator is noise)
@@ -19,7 +31,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("fetch_counters.csv", "write_counters.csv"):
     for r in csv.DictReader(open(os.path.join(src, name))):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"tag": tag, "frames_per_launch": frames, "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3 (MI355X_MICROARCH.md: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); "
+out = {"tag": tag, "frames_per_launch": frames, "build": run.get("build"), "batches_in_flight": run.get("batches_in_flight"),
+       "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --profile-run --steps %s --warmup %s" % (run.get("steps"), run.get("warmup")),
+       "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3 (MI355X_MICROARCH.md: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); "
        "the guide's x2 correction for FETCH_SIZE applies to 16 B/lane streaming reads: applied to the wide threshold kernel only; "
        "raw and x2-corrected values are both listed", "kernels": {}}
 with open(os.path.join("profiles", tag + "_pmc.csv"), "w", newline="") as f:
