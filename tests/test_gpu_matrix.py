@@ -71,6 +71,34 @@ def test_parameter_matrix_on_1080p_batches(env, case):
         assert found >= 15 * NF          # the adaptive settings find nearly every rendered marker
 
 
+def test_zero_distortion_vector_with_poses_equals_the_oracle(env):
+    """Config 3's first form (intrinsics with dist = zeros(5)): a NON-EMPTY distortion vector of zeros takes the undistort / distort
+    branches of LINES (markerdetector.cpp:956-959, 989-991) and of solvePnP with a model that changes nothing - compared with the oracle WITH
+    poses on the 1080p frames (round 3 compared this case only between two HIP handles)."""
+    capi, orc = env["capi"], env["orc"]
+    zeros = [0.0] * 5
+    h = capi.Handle(1920, 1080, max_batch=NF)
+    try:
+        got = h.detect_batch_host(env["frames"], K=K, dist=zeros, marker_size=0.05)
+        nodist = h.detect_batch_host(env["frames"], K=K, dist=None, marker_size=0.05)
+    finally:
+        h.close()
+    o = orc.Oracle()
+    found = 0
+    for f in range(NF):
+        ref = o.detect(env["frames"][f], K=K, dist=zeros, marker_size=0.05)
+        assert [int(m["id"]) for m in got[f]] == [m["id"] for m in ref] == [int(m["id"]) for m in nodist[f]], f
+        for a, b, c in zip(got[f], ref, nodist[f]):
+            ca, cb = np.asarray(a["corners"], float).reshape(4, 2), np.asarray(b["corners"], float).reshape(4, 2)
+            assert np.max(np.abs(ca - cb) / np.maximum(np.abs(cb), 1.0)) < 1e-4, f
+            assert int(a["has_pose"]) == 1
+            assert rel_err(a["rvec"], b["rvec"]) < 1e-4 and rel_err(a["tvec"], b["tvec"]) < 1e-4, f
+            # and the zero model is (numerically) no model: the same pose as without a distortion vector
+            assert rel_err(a["tvec"], c["tvec"]) < 1e-4, f
+        found += len(ref)
+    assert found >= 15 * NF
+
+
 # (width, height, row stride, x offset, y offset) of a window of the 1080p frames, handed over with that row stride
 GEOMETRIES = [
     (1283, 727, 1283, 300, 200),     # odd width and stride: byte-wise threshold kernel

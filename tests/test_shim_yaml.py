@@ -20,6 +20,16 @@ def wrap(vals, per=3):
 def test_shim_yaml_readers(tmp_path):
     from aruco_amd import build_library
     build_library()
+    exe = tmp_path / "shim_yaml"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_yaml.cpp"), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    run_shim_yaml(exe, tmp_path)
+
+
+def run_shim_yaml(exe, tmp_path, env=None):
+    """Writes the YAML files, runs the built caller on them and checks what it printed (also used by the sanitizer build of the same
+    caller, tests/test_oracle_sanitized.py)."""
     doc = json.load(open(os.path.join(GOLDEN, "board.json")))
     intr, bc = doc["intrinsics"], doc["board_conf"]
     with open(tmp_path / "intrinsics.yml", "w") as f:
@@ -32,10 +42,6 @@ def test_shim_yaml_readers(tmp_path):
         for i, o in zip(bc["ids"], bc["obj"]):
             c = ["[ %s ]" % ", ".join("%d." % int(v) if float(v) == int(v) else repr(float(v)) for v in p) for p in o]
             f.write("   - { id:%d, corners:[ %s, %s, [\n       %s ], %s ] }\n" % (i, c[0], c[1], c[2][2:-2], c[3]))
-    exe = tmp_path / "shim_yaml"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "shim_yaml.cpp"), "-o", str(exe),
-                    "-L" + os.path.join(ROOT, "aruco_amd"), "-larucohip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "aruco_amd"),
-                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
     bad = []
     for k, text in enumerate(["", "%YAML:1.0\nimage_width: 640\nimage_height: 480\ncamera_matrix: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ 1., 2. ]\n",
                               "%YAML:1.0\naruco_bc_nmarkers: 2\naruco_bc_mInfoType: 0\naruco_bc_markers:\n   - { id:1, corners:[ [ 0., 0., 0. ], [ 1., 0., 0. ] ] }\n",
@@ -44,7 +50,9 @@ def test_shim_yaml_readers(tmp_path):
         path.write_text(text)
         bad.append(str(path))
     bad.append(str(tmp_path / "does_not_exist.yml"))
-    out = subprocess.run([str(exe), str(tmp_path / "intrinsics.yml"), str(tmp_path / "board.yml")] + bad, stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    r = subprocess.run([str(exe), str(tmp_path / "intrinsics.yml"), str(tmp_path / "board.yml")] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    out = r.stdout.splitlines()
     assert [int(v) for v in out[0].split()] == [intr["width"], intr["height"]]
     assert np.array_equal(np.array(out[1].split(), np.float32), np.array(intr["K"], np.float32))
     assert np.array_equal(np.array(out[2].split(), np.float32), np.array(intr["dist"], np.float32))
