@@ -537,7 +537,9 @@ class Handle:
     def debug_counters(self):
         c = np.zeros(8, np.uint32)
         self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
-        return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3])}
+        return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3]),
+                # walker mode: [4] = long walks (checkpoint rings handed out); a -DWALK_STATS variant build also counts the border steps
+                "long_walks": int(c[4]), "first_pass_steps": int(c[5]), "generation_steps": int(c[6]), "generation_lane_slots": int(c[7])}
 
     def gl_modelview_batch(self, nframes, cap=64):
         """Marker::glGetModelViewMatrix for every marker of the last batch (device kernel): list per frame of [n][16]."""

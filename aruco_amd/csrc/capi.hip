@@ -34,6 +34,7 @@ Tuning read_tuning() {
     t.cand_chunks = std::max(1, geti("ARUCOHIP_CAND_CHUNKS", 16));
     t.leash = geti("ARUCOHIP_LEASH", 0);
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
+    t.pull_q = geti("ARUCOHIP_PULL_Q", 1);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
@@ -144,6 +145,15 @@ struct arucohip_handle {
     bool thres_bytes = true;             // buf.thres holds the last batch's byte image (else: tiles + buf.thres_edge, expanded on demand)
     hipEvent_t wait_thr = nullptr;       // set by detect_batch: event the next threshold kernel waits for
     int last_chunks = 1, last_per = 0;   // chunks and frames per chunk of the last batch
+    // One frame per call (the reference's call shape, arucohip_detect): the chain of ~20 dependent dispatches of a frame is captured once per
+    // (geometry, parameters, camera) into a hipGraph and replayed with ONE launch per call; the frame's H2D copy stays outside (its source
+    // pointer changes with every call), the results land in the handle's pinned staging inside the graph.
+    struct FrameGraph {
+        hipGraphExec_t exec = nullptr;
+        uint64_t key = 0;          // digest of everything the captured launches carry by value
+        uint64_t seen = 0;         // key of the previous eager call: the second call with the same key captures (buffers are sized by then)
+        int disabled = 0;          // ARUCOHIP_GRAPH=0, or a capture failed once
+    } fgraph;
     // Batches in flight (arucohip_set_pipeline_depth / _submit / _wait): every pipeline lane is a complete worker (own
     // buffers, own stream); ticket t runs on lane t mod depth, so the latency-bound tail of batch t (border following,
     // decoding) overlaps the bandwidth-bound head of batch t+1.
@@ -257,6 +267,8 @@ static void free_all(arucohip_handle* h) {
     h->lanes.clear();
     if (h->retry) arucohip_destroy(h->retry);
     h->retry = nullptr;
+    if (h->fgraph.exec) hipGraphExecDestroy(h->fgraph.exec);
+    h->fgraph.exec = nullptr;
     if (h->ev_submit) hipEventDestroy(h->ev_submit);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_thr) hipEventDestroy(h->ev_thr);
@@ -334,6 +346,10 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     const size_t F = h->cap_frames, P = F * lim->max_thres_planes, px = (size_t)lim->max_width * lim->max_height;
     Buffers& b = h->buf;
     b.tune = read_tuning();
+    {
+        const char* eg = getenv("ARUCOHIP_GRAPH");
+        h->fgraph.disabled = (eg && *eg && atoi(eg) == 0) ? 1 : 0;
+    }
     b.cap_raw = (uint32_t)lim->triggers_per_frame;
     b.cap_trig = (uint32_t)std::max(lim->triggers_per_frame, 8192);   // two halves: outer starts, hole starts
     b.long_cap = (uint32_t)std::min(std::max(lim->long_walks_per_plane, 64), 1 << 16);
@@ -1011,6 +1027,71 @@ static int collect_batch_host(arucohip_handle* h, int nframes, arucohip_marker_t
     return ret;
 }
 
+// FNV-1a over the bytes of everything a captured launch carries by value
+static uint64_t digest(uint64_t hsh, const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) hsh = (hsh ^ c[i]) * 1099511628211ull;
+    return hsh;
+}
+
+// arucohip_detect on one host frame through a captured graph. *handled = false: the caller takes the eager path (first call of a
+// configuration, timing on, a decoder or threshold method that blocks the host, a failed capture). The frame's copy to the device is issued
+// eagerly in front of the graph; inside it: the counters' memset, every kernel of detect_core (with the fork to the side stream of the late
+// walker generations) and the three copies of the results into the handle's pinned staging.
+static int detect_one_graphed(arucohip_handle* h, const uint8_t* frame, int W, int H, size_t row_stride, int channels, const DetectParams& dp, const CamModel& cam,
+                              arucohip_marker_t* out, int cap, int32_t* n_out, bool* handled) {
+    *handled = false;
+    if (h->fgraph.disabled || h->timing || dp.decoder == ARUCOHIP_DECODER_USER || dp.thres_method == ARUCOHIP_THRES_CANNY || h->params.erode) return ARUCOHIP_OK;
+    uint64_t key = 1469598103934665603ull;
+    const int geo[4] = {W, H, channels, (int)h->buf.seg_mode};
+    key = digest(key, geo, sizeof(geo));
+    key = digest(key, &dp, sizeof(dp));
+    key = digest(key, &cam, sizeof(cam));
+    key = digest(key, &h->stream, sizeof(h->stream));
+    if (h->fgraph.exec && h->fgraph.key != key) {   // another configuration: start over
+        (void)hipGraphExecDestroy(h->fgraph.exec);
+        h->fgraph.exec = nullptr, h->fgraph.seen = 0;
+    }
+    if (!h->fgraph.exec && h->fgraph.seen != key) {   // first call with this configuration: eager (it sizes every buffer), remember it
+        h->fgraph.seen = key;
+        return ARUCOHIP_OK;
+    }
+    int rc;
+    const uint8_t* gray_dev;
+    FrameGeom g;
+    if ((rc = stage_frames(h, frame, 1, W, H, row_stride, (size_t)H * row_stride, 0, channels, &gray_dev, &g))) return rc;   // H2D (+ BGR conversion), eager
+    h->last_chunks = 1, h->last_per = 1;
+    if (!h->fgraph.exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->fgraph.disabled = 1;
+            return ARUCOHIP_OK;   // the frame is staged; the eager path stages it again, which is harmless
+        }
+        rc = detect_core(h, gray_dev, g, 1, dp, cam);
+        const Buffers& b = h->buf;
+        hipError_t e = hipSuccess;
+        if (rc == ARUCOHIP_OK) {
+            e = hipMemcpyAsync(h->h_markers, b.markers, (size_t)b.cap_markers * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->h_n, b.nmarkers, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        }
+        const hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+        if (rc != ARUCOHIP_OK || e != hipSuccess || e2 != hipSuccess || !graph || hipGraphInstantiate(&h->fgraph.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            h->fgraph.exec = nullptr, h->fgraph.disabled = 1;   // this handle stays on the eager path
+            return ARUCOHIP_OK;
+        }
+        (void)hipGraphDestroy(graph);
+        h->fgraph.key = key;
+    }
+    *handled = true;
+    HIPCHK(h, hipGraphLaunch(h->fgraph.exec, h->stream));
+    h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = dp.nthr, h->last_gray = gray_dev, h->last_geom = g;
+    return collect_batch_host(h, 1, out, cap, n_out);
+}
+
 static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nframes, int W, int H, size_t row_stride, size_t frame_stride,
                              int frames_on_device, int channels, const float* K, const float* dist, int ndist, float marker_size, int y_perp,
                              arucohip_marker_t* out, int cap, int32_t* n_out, int out_on_device, bool defer = false) {
@@ -1022,6 +1103,11 @@ static int detect_batch_impl(arucohip_handle* h, const uint8_t* frames, int nfra
     CamModel cam;
     if ((rc = make_detect_params(h, W, H, &dp))) return rc;
     if ((rc = make_cam(h, K, dist, ndist, marker_size, y_perp, &cam))) return rc;
+    if (nframes == 1 && !frames_on_device && !out_on_device && !defer && h->nsub == 1) {
+        bool handled = false;
+        rc = detect_one_graphed(h, frames, W, H, row_stride, channels, dp, cam, out, cap, n_out, &handled);
+        if (handled) return rc;
+    }
     // chunks of equal size, as few as the workers' buffers allow but one per worker when the batch is large enough to share
     int chunks = (nframes + h->cap_frames - 1) / h->cap_frames;
     if (h->nsub > 1 && (size_t)nframes * W * H >= (size_t)h->nsub * 32 * 1024 * 1024) chunks = std::max(chunks, std::min(h->nsub, nframes));
@@ -1340,26 +1426,31 @@ int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
     h = active(h);
     HIPCHK(h, hipSetDevice(h->device));
     uint64_t acc[CNT_FIXED] = {};
-    uint64_t ntrig = 0, nraw = 0;
+    uint64_t ntrig = 0, nraw = 0, nlong = 0, first_steps = 0;
     for (int c = 0; c < std::max(h->last_chunks, 1); c++) {
         arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
         uint32_t cnt[CNT_FIXED];
         HIPCHK(h, hipMemcpyAsync(cnt, w->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, w->stream));
         int planes = std::max(w->last_frames * w->last_nthr, 1);
-        std::vector<uint32_t> tc((size_t)planes * TRIG_CNT_STRIDE), rc_((size_t)planes * TRIG_CNT_STRIDE);
+        std::vector<uint32_t> tc((size_t)planes * TRIG_CNT_STRIDE), rc_((size_t)planes * TRIG_CNT_STRIDE), rg((size_t)planes * TRIG_CNT_STRIDE);
         HIPCHK(h, hipMemcpyAsync(tc.data(), w->buf.trig_cnt, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
         HIPCHK(h, hipMemcpyAsync(rc_.data(), w->buf.raw_cnt, rc_.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(h, hipMemcpyAsync(rg.data(), w->buf.ring_cnt, rg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
         HIPCHK(h, hipStreamSynchronize(w->stream));
-        for (int i = 0; i < CNT_FIXED; i++) acc[i] = (i == CNT_STATUS) ? (acc[i] | cnt[i]) : acc[i] + cnt[i];
+        for (int i = 0; i < CNT_FIXED; i++)
+            if (i != 1 && i != 2) acc[i] = (i == CNT_STATUS) ? (acc[i] | cnt[i]) : acc[i] + cnt[i];   // [1], [2] come from the planes' own counters below
         for (int p = 0; p < planes; p++) {
             ntrig += tc[(size_t)p * TRIG_CNT_STRIDE] + tc[(size_t)p * TRIG_CNT_STRIDE + 1];
             acc[1] += tc[(size_t)p * TRIG_CNT_STRIDE + TC_CDESC], acc[2] += tc[(size_t)p * TRIG_CNT_STRIDE + TC_POOL];
             nraw += rc_[(size_t)p * TRIG_CNT_STRIDE];
+            nlong += rg[(size_t)p * TRIG_CNT_STRIDE] + rg[(size_t)p * TRIG_CNT_STRIDE + 1];
         }
+        first_steps += cnt[CNT_STAT_FIRST];
     }
     for (int i = 0; i < CNT_FIXED; i++) out8[i] = (uint32_t)std::min<uint64_t>(acc[i], 0xFFFFFFFFu);
     out8[0] = (uint32_t)std::min<uint64_t>(ntrig, 0xFFFFFFFFu);   // start candidates after the run rule (all planes)
-    out8[4] = (uint32_t)std::min<uint64_t>(nraw, 0xFFFFFFFFu);    // waypoint records (segment mode)
+    out8[4] = (uint32_t)std::min<uint64_t>(h->buf.seg_mode ? nraw : nlong, 0xFFFFFFFFu);   // waypoint records (segment mode) / long walks = checkpoint rings handed out
+    out8[5] = (uint32_t)std::min<uint64_t>(first_steps, 0xFFFFFFFFu);   // -DWALK_STATS variant: border steps of the first walker pass (else 0); [6], [7]: see internal.h
     return ARUCOHIP_OK;
 }
 

@@ -426,8 +426,10 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
     a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig;
     a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
     const int ntiles = (a.tnx - 1) * (a.tny - 1);
-    const int maxchunks = b.tune.cand_chunks;
-    const int chunks = std::max(1, std::min(maxchunks, (ntiles + 4 * CAND_THREADS - 1) / (4 * CAND_THREADS)));
+    // a single frame has the chip to itself: a tile per thread; a batch of planes: four tiles per thread, at most cand_chunks workgroups per plane
+    const int maxchunks = nplanes <= 2 ? 256 : b.tune.cand_chunks;
+    const int per = nplanes <= 2 ? CAND_THREADS : 4 * CAND_THREADS;
+    const int chunks = std::max(1, std::min(maxchunks, (ntiles + per - 1) / per));
     hipLaunchKernelGGL(candidates_kernel, dim3(chunks, nplanes), dim3(CAND_THREADS), 0, s, a);
 }
 
@@ -456,6 +458,7 @@ struct WalkArgs {
     int leash;             // steps every candidate gets in the first pass
     int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
     int gen_blocks;        // 64-lane workgroups per kind in this launch (each loops over its share of the list)
+    int pull_q;            // a wave's slice of the list is 64 * pull_q entries: its lanes take the slice's next entry when their walk ends
     uint32_t long_cap;     // rings per plane and kind
     uint32_t* ring_cnt;   // per plane line: rings handed out (outer, hole)
     uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
@@ -522,6 +525,51 @@ constexpr int CHUNK = CHUNK_N;   // steps taken between two looks at the block e
                                  // bytes - +1.2 % on the bench's stream, -17 % on the cluttered one (148k against 178k frames/s: many short, wiggly borders pay
                                  // the edge tests twice as often). 8 stays.
 
+// CHUNK border steps of every walking lane inside its 32x32 block, without edge tests (the caller has made room). The walk lives in block
+// coordinates (bits_tiles.h: lp, s1c); p0b / p1b / tkb are the start pixel, the start's predecessor and the trigger in the same coordinates. n is a
+// multiple of CHUNK at a chunk start, so the checkpoint of every CK-th step is stored there: ck_at(n / CK) is where this lane's goes.
+template <bool HOLE, int LANES, typename CkAt>
+__device__ __forceinline__ void walk_chunk(const uint32_t* rb, uint32_t base1, uint32_t p0b, uint32_t p1b, uint32_t tkb, uint32_t pos0, uint32_t lim, uint32_t& lp,
+                                           uint32_t& s1c, uint32_t& n, bool& walking, bool& was_bad, bool& was_closed, CkAt ck_at) {
+#pragma unroll
+    for (int j = 0; j < CHUNK; j++) {
+        if (walking) {
+            if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(lp + base1, tb_s_of(s1c));
+            const uint32_t* r = rb + (lp >> 16) * LANES;
+            const uint32_t up = __builtin_amdgcn_ubfe(r[0], lp, 3u), mid = __builtin_amdgcn_ubfe(r[LANES], lp, 3u), dn = __builtin_amdgcn_ubfe(r[2 * LANES], lp, 3u);
+            // ring E,NE,N,NW,W,SW,S,SE: the reversed `up` lands on bits 1..3
+            const uint32_t m = (__builtin_bitreverse32(up) >> 28) | (mid >> 2) | ((mid & 1u) << 4) | (dn << 5);
+            // walk_step<HOLE, false> on the selector-shaped direction state: the search starts at rotation (s + 1) & 7 = the state's low bits
+            const uint32_t rot = (m | (m << 8)) >> (s1c & 31u);
+            const uint32_t k = (uint32_t)__builtin_ctz(rot);   // a pixel of a border that is being followed has a neighbour
+            bool bad;
+            if (HOLE) {
+                // examined 4-neighbours z = pos + off precede tkey iff delta = pos - tkey < -off; N < W < E < S in raster order
+                const int delta = (int)(lp - tkb);
+                uint32_t hit = 0;   // an integer, not a flag, crosses the branch: a flag would be turned into one and back
+                if (delta < 65536) {                       // only near or above the trigger row
+                    uint32_t ex;                           // ((1 << k) - 1) << sh: directions examined and found empty
+                    asm("v_bfm_b32 %0, %1, %2" : "=v"(ex) : "v"(k), "v"(s1c));   // uses the low 5 bits of both, and the state's are (s + 1) & 7
+                    const uint32_t cm = 4u | (delta < 1 ? 16u : 0u) | (delta < -1 ? 1u : 0u) | (delta < -65536 ? 64u : 0u);
+                    hit = (ex | (ex >> 8)) & cm;
+                }
+                asm volatile("" : "+v"(hit));   // keeps the compare below the branch, where its result is a lane mask
+                bad = hit != 0;
+            } else {
+                bad = lp + base1 < pos0;
+            }
+            const uint32_t ns1c = ((s1c + k + 5u) & 7u) | TB_S1C;   // d = (sh + k) & 7, back direction (d + 4) & 7, next rotation (d + 5) & 7
+            const uint32_t nb = __builtin_amdgcn_perm(0x01021222u, 0x21201000u, ns1c);
+            const uint32_t nlp = lp + ((nb | (nb << 12)) & 0x000F000Fu) - 65537u;
+            ++n;
+            const bool closed = nlp == p0b && lp == p1b;
+            was_bad |= bad, was_closed |= closed;
+            walking = !(bad | closed | (n >= lim));
+            lp = nlp, s1c = ns1c;   // also when the walk has ended: position and direction only matter to a walk that goes on (WR_LIMIT)
+        }
+    }
+}
+
 // Follows one border per lane until every lane's walk has ended: proven not to be the scan's start (WR_BAD), closed
 // (WR_CLOSED) or n == lim (WR_LIMIT, state advanced so that the walk can be resumed). All lanes of the wave step together.
 // The per-lane 32x32 block is re-centred (by all lanes at once) when a walking lane is within CHUNK pixels of its edge,
@@ -567,43 +615,7 @@ __device__ __forceinline__ int walk_run(const uint64_t* __restrict__ tiles, int 
                 p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
             }
         }
-#pragma unroll
-        for (int j = 0; j < CHUNK; j++) {
-            if (walking) {
-                if (j == 0 && (n & (CK - 1)) == 0) *ck_at(n / CK) = pack_ck(lp + base1, tb_s_of(s1c));
-                const uint32_t* r = rb + (lp >> 16) * LANES;
-                const uint32_t up = __builtin_amdgcn_ubfe(r[0], lp, 3u), mid = __builtin_amdgcn_ubfe(r[LANES], lp, 3u), dn = __builtin_amdgcn_ubfe(r[2 * LANES], lp, 3u);
-                // ring E,NE,N,NW,W,SW,S,SE: the reversed `up` lands on bits 1..3
-                const uint32_t m = (__builtin_bitreverse32(up) >> 28) | (mid >> 2) | ((mid & 1u) << 4) | (dn << 5);
-                // walk_step<HOLE, false> on the selector-shaped direction state: the search starts at rotation (s + 1) & 7 = the state's low bits
-                const uint32_t rot = (m | (m << 8)) >> (s1c & 31u);
-                const uint32_t k = (uint32_t)__builtin_ctz(rot);   // a pixel of a border that is being followed has a neighbour
-                bool bad;
-                if (HOLE) {
-                    // examined 4-neighbours z = pos + off precede tkey iff delta = pos - tkey < -off; N < W < E < S in raster order
-                    const int delta = (int)(lp - tkb);
-                    uint32_t hit = 0;   // an integer, not a flag, crosses the branch: a flag would be turned into one and back
-                    if (delta < 65536) {                       // only near or above the trigger row
-                        uint32_t ex;                           // ((1 << k) - 1) << sh: directions examined and found empty
-                        asm("v_bfm_b32 %0, %1, %2" : "=v"(ex) : "v"(k), "v"(s1c));   // uses the low 5 bits of both, and the state's are (s + 1) & 7
-                        const uint32_t cm = 4u | (delta < 1 ? 16u : 0u) | (delta < -1 ? 1u : 0u) | (delta < -65536 ? 64u : 0u);
-                        hit = (ex | (ex >> 8)) & cm;
-                    }
-                    asm volatile("" : "+v"(hit));   // keeps the compare below the branch, where its result is a lane mask
-                    bad = hit != 0;
-                } else {
-                    bad = lp + base1 < pos0;
-                }
-                const uint32_t ns1c = ((s1c + k + 5u) & 7u) | TB_S1C;   // d = (sh + k) & 7, back direction (d + 4) & 7, next rotation (d + 5) & 7
-                const uint32_t nb = __builtin_amdgcn_perm(0x01021222u, 0x21201000u, ns1c);
-                const uint32_t nlp = lp + ((nb | (nb << 12)) & 0x000F000Fu) - 65537u;
-                ++n;
-                const bool closed = nlp == p0b && lp == p1b;
-                was_bad |= bad, was_closed |= closed;
-                walking = !(bad | closed | (n >= lim));
-                lp = nlp, s1c = ns1c;   // also when the walk has ended: position and direction only matter to a walk that goes on (WR_LIMIT)
-            }
-        }
+        walk_chunk<HOLE, LANES>(rb, base1, p0b, p1b, tkb, pos0, lim, lp, s1c, n, walking, was_bad, was_closed, ck_at);
     }
     const int res = was_bad ? WR_BAD : was_closed ? WR_CLOSED : WR_LIMIT;
     pos = lp + base1, s = tb_s_of(s1c);
@@ -686,6 +698,13 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
         int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s,
                                      [&](uint32_t q) { return ck0 + q * 64 + lane; }, &blk);
         if (!live) res = WR_BAD;
+#ifdef WALK_STATS
+        {
+            uint32_t st = live ? n : 0u;
+            for (int o = 32; o > 0; o >>= 1) st += __shfl_xor(st, o, 64);
+            if (lane == 0) atomicAdd(&a.counters[CNT_STAT_FIRST], st);
+        }
+#endif
         // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
         {
             bool longw = live && res == WR_LIMIT && n < nmax;
@@ -743,9 +762,14 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
 }
 
 // Kernel 2b, one launch per generation: the walks that are still open after the previous generation, from all planes, as
-// one dense list per kind. Every wave takes 64 of them, walks at most gen_steps steps and appends the survivors (with
-// their state) to the next generation's list, so wavefronts are full apart from the walks that end inside a generation;
-// the generations grow from 64 steps (many walks alive) to thousands (a handful of very long borders).
+// one dense list per kind; survivors (with their state) are appended to the next generation's list.
+// Round 4: a wave owns a SLICE of 64 * pull_q consecutive list entries and every lane whose walk has ended takes the slice's next entry (taking
+// over a walk costs what a re-centring costs - the block load it needs anyway -, no atomics are involved, and which lane follows which border
+// changes nothing in the results). With pull_q = 1 this is round 3's "64 walks per wave". Measured on the bench stream with a -DWALK_STATS build
+// (profiles/r04_walker_steps.txt): per frame 20.4 k border steps in the first pass and 65.1 k in the generations; the generations' waves spend
+// 108 k lane-step slots on them with pull_q = 1 (60 % of the lanes busy), 95 k with 2, 82 k with 4 - and run 0.64 / 0.84 / 1.07 ms: fewer, fuller
+// waves are SLOWER. Every generation wave is resident at once, so the time is the number of iterations of the longest walk times the latency of an
+// iteration (a block load from HBM under load plus eight dependent steps), not the lane-step slots. pull_q stays 1; the knob is kept.
 template <bool HOLE>
 __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, uint32_t* rows) {
     const int kind = HOLE ? 1 : 0, lane = threadIdx.x;
@@ -753,34 +777,94 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
     const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap, dst = ((size_t)kind * 2 + ((a.gen + 1) & 1)) * a.gen_cap;
     const uint32_t nmax = (uint32_t)a.max_contour;
     const size_t plane_tiles = (size_t)a.tnx * a.tny;
-    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += (uint32_t)a.gen_blocks * 64u) {
-        const bool live = base + lane < count;
-        const uint4 st = live ? a.gen_state[src + base + lane] : make_uint4(0x00200021u, 0x00200020u, 0u, 0u);
-        const uint32_t ring = live ? a.gen_ring[src + base + lane] : 0u;
-        const uint32_t tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
-        uint32_t pos = st.y, n = st.w & 0xFFFFu;
-        int s = (int)(st.w >> 16);
-        const int plane = (int)(ring / (2u * a.long_cap));
-        const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * plane_tiles;
-        uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
-        const uint32_t lim = min(n + (uint32_t)a.gen_steps, nmax);
-        const int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s, [&](uint32_t q) { return ck + q; });
-        if (live && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
-            uint32_t at;
-            keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
-        }
-        const bool again = live && res == WR_LIMIT && n < nmax;
-        const unsigned long long bal = __ballot(again);
-        if (bal) {
-            uint32_t at0 = 0;
-            if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
-            at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
-            if (again) {
-                const size_t li = dst + at0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));   // at most as many entries as this list had
-                a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
-                a.gen_ring[li] = ring;
+    const int maxbx = (a.tnx - 4) * 8, maxby = (a.tny - 4) * 8;
+    const uint32_t slice = 64u * (uint32_t)a.pull_q;
+    const uint32_t* rb = rows + lane - 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t first = (uint32_t)chunk * slice; first < count; first += (uint32_t)a.gen_blocks * slice) {
+        const uint32_t end = min(first + slice, count);
+        uint32_t next = first;   // wave-uniform: the slice's next entry nobody has taken
+        // the lane's walk (valid while `walking`)
+        bool walking = false, was_bad = false, was_closed = false;
+        uint32_t tkey = 0, pos0 = 0, pos1 = 0, n = 0, lim = 0, ring = 0, lp = 0, s1c = TB_S1C, base1 = 0, p0b = 0, p1b = 0, tkb = 0;
+        int plane = 0;
+        const uint64_t* __restrict__ tiles = a.tiles;
+        uint32_t* ck = a.scratch;
+        TileBlock blk;
+        blk.bx = blk.by = 0;
+#ifdef WALK_STATS   // variant build only (tools/build_variant.sh walkstats -DWALK_STATS): border steps walked and lane-step slots spent by the generations
+        uint32_t st_steps = 0, st_iters = 0;
+#endif
+        for (;;) {
+            // ---- idle lanes take the next entries of the slice
+            bool fresh = false;
+            {
+                const unsigned long long idle = __ballot(!walking);
+                if (idle && next < end) {
+                    const uint32_t idx = next + (uint32_t)__popcll(idle & below);
+                    if (!walking && idx < end) {
+                        const uint4 st = a.gen_state[src + idx];
+                        ring = a.gen_ring[src + idx];
+                        tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
+                        n = st.w & 0xFFFFu, s1c = tb_s1c((int)(st.w >> 16));
+                        plane = (int)(ring / (2u * a.long_cap));
+                        tiles = a.tiles + (size_t)plane * plane_tiles;
+                        ck = a.scratch + (size_t)ring * a.maxck;
+                        lim = min(n + (uint32_t)a.gen_steps, nmax);
+                        base1 = 0, lp = st.y;   // the position as it is until the block is placed
+                        walking = n < lim, fresh = true, was_bad = false, was_closed = false;
+                    }
+                    next = min(end, next + (uint32_t)__popcll(idle));
+                }
+            }
+            if (!__any(walking)) break;
+            const bool had = walking;
+            {
+                // a side that is clamped to the image needs no margin: the border cannot leave the image
+                const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
+                const bool near = (lxm < CHUNK && blk.bx > 0) || (lxm > 29 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) || (ly > 30 - CHUNK && blk.by < maxby);
+                const uint32_t at = lp + base1;
+                {
+                    // a closed border that reaches Chebyshev distance d from its start has at least 2 d points (walk_run)
+                    const int ax = abs((int)(at & 0xFFFFu) - (int)(pos0 & 0xFFFFu)), ay = abs((int)(at >> 16) - (int)(pos0 >> 16));
+                    if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, was_bad = true;
+                }
+                if (walking && (near || fresh)) {
+                    tb_load_dir<64, CHUNK>(tiles, a.tnx, a.tny, at, tb_s_of(s1c), rows, lane, blk);
+                    base1 = tb_base1(blk), lp = at - base1;
+                    p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
+                }
+            }
+#ifdef WALK_STATS
+            const uint32_t n_before = n;
+#endif
+            walk_chunk<HOLE, 64>(rb, base1, p0b, p1b, tkb, pos0, lim, lp, s1c, n, walking, was_bad, was_closed, [&](uint32_t q) { return ck + q; });
+#ifdef WALK_STATS
+            st_steps += had ? n - n_before : 0u, st_iters++;
+#endif
+            // ---- walks that ended in this chunk: a closed border inside the size filter is kept, a walk at its limit goes on in the next generation
+            const bool ended = had && !walking;
+            if (ended && !was_bad && was_closed && n < nmax && (int)n > a.min_contour) {
+                uint32_t at_;
+                keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at_);
+            }
+            const bool again = ended && !was_bad && !was_closed && n < nmax;
+            const unsigned long long bal = __ballot(again);
+            if (bal) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                if (again) {
+                    const size_t li = dst + at0 + (uint32_t)__popcll(bal & below);   // at most as many entries as this list had
+                    a.gen_state[li] = make_uint4(tkey, lp + base1, pos1, n | ((uint32_t)tb_s_of(s1c) << 16));
+                    a.gen_ring[li] = ring;
+                }
             }
         }
+#ifdef WALK_STATS
+        for (int o = 32; o > 0; o >>= 1) st_steps += __shfl_xor(st_steps, o, 64);
+        if (lane == 0) atomicAdd(&a.counters[CNT_STAT_STEPS], st_steps), atomicAdd(&a.counters[CNT_STAT_SLOTS], st_iters * (uint32_t)(CHUNK * 64));
+#endif
     }
 }
 
@@ -863,7 +947,8 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
         // plane's ~1000 candidates reach generation 1), fewer for the thin late generations; surplus workgroups exit at once
         const int before = done - a.gen_steps;   // steps every walk of this generation has behind it
         const int per_plane_x16 = before < 200 ? 64 : before < 450 ? 40 : before < 1100 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
-        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2));
+        a.pull_q = std::max(1, std::min(16, b.tune.pull_q));
+        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2 / a.pull_q));
         hipLaunchKernelGGL(walker_long_kernel, dim3(2 * a.gen_blocks), dim3(64), 0, cur, a);
     }
     if (forked) (void)hipEventRecord(fk.joined, fk.side);
@@ -1191,8 +1276,10 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.tiles = b.tiles, a.tnx = tiles_x(g.width), a.tny = tiles_y(g.height), a.from_pool = b.seg_mode, a.cdesc = b.cdesc, a.pool = b.pool, a.quads = b.quads, a.counters = b.counters;
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
-    const int qb = b.tune.quad_blocks;
-    a.qblocks = pass == 2 ? std::max(1, qb / 2) : qb, a.nplanes = nframes * p.nthr;
+    a.nplanes = nframes * p.nthr;
+    // a handful of planes (one detect() per frame): a wave per kept border instead of a few waves that take the borders one after the other
+    const int qb = a.nplanes <= 2 ? 128 : a.nplanes <= 8 ? 48 : b.tune.quad_blocks;
+    a.qblocks = pass == 2 ? std::max(1, qb / 2) : qb;
     const int planes8 = ((a.nplanes + 7) / 8) * 8;
     hipLaunchKernelGGL(contour_quad_kernel, dim3(planes8 * a.qblocks), dim3(64), 0, s, a);
 }

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     const double scale = 1. / npx;
     const double mu = (double)(uint32_t)a.othr[idx] * scale;
     double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    bool done = false;
     constexpr int DW = OTSU_BINS / 2;          // dwords of a candidate's row per stage
     constexpr int CPL = 64 / DW;               // candidates a load instruction covers
     for (int stage = 0; stage < 256 / OTSU_BINS; stage++) {
@@ -339,18 +340,42 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
             }
         }
         __syncthreads();
-        if (lane < cnt) {
+        if (lane < cnt && !done) {
             const uint16_t* h = sh + lane;
-            for (int ii = 0; ii < OTSU_BINS; ii++) {
+            // The sweep is a chain of dependent fp64 divisions, one per bin (OpenCV's recurrence is order-dependent, so every bin that changes the
+            // state must be taken in order). A patch of a marker has two clusters of grey levels: most bins are EMPTY, and an empty bin (p_i = 0)
+            // only replaces mu1 by fl(fl(mu1 * q1) / q1): once that leaves mu1 unchanged, the state and sigma are those of the bin before - whose
+            // sigma the maximum already holds, and a tie does not move it - so the rest of the run of empty bins is skipped. Before the first
+            // occupied bin q1 = 0 and mu1 = 0 stay what they are; behind the last one q1 > 1 - eps holds for good and nothing is evaluated any
+            // more. Bit-identical to the plain sweep (tests/test_gpu_parity.py compares ids and thresholds with the oracle's), a third of its steps.
+            unsigned long long occ = 0;
+#pragma unroll 16
+            for (int ii = 0; ii < OTSU_BINS; ii++) occ |= (unsigned long long)(h[ii * OTSU_PITCH] != 0) << ii;
+            for (int ii = 0; ii < OTSU_BINS;) {
                 const int i = stage * OTSU_BINS + ii;
-                double p_i = h[ii * OTSU_PITCH] * scale;
+                const bool empty = !((occ >> ii) & 1ull);
+                const int run_end = empty ? ((occ >> ii) ? ii + (int)__builtin_ctzll(occ >> ii) : OTSU_BINS) : ii + 1;   // first bin behind this run of empty bins
+                const double p_i = empty ? 0. : h[ii * OTSU_PITCH] * scale;
+                const double mu1_in = mu1;
                 mu1 *= q1;
                 q1 += p_i;
-                double q2 = 1. - q1;
-                if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+                const double q2 = 1. - q1;
+                ii++;
+                if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) {
+                    if (q1 > 0.5) {   // all the mass is behind: every later bin takes this branch too and mu1 is never read again
+                        done = true;
+                        break;
+                    }
+                    if (empty) ii = run_end;   // q1 = 0: mu1 = 0 * 0 stays 0 through the run
+                    continue;
+                }
                 mu1 = (mu1 + i * p_i) / q1;
-                double mu2 = (mu - q1 * mu1) / q2;
-                double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                if (empty && mu1 == mu1_in) {   // fixed point: the remaining empty bins of the run change nothing
+                    ii = run_end;
+                    continue;
+                }
+                const double mu2 = (mu - q1 * mu1) / q2;
+                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
                 if (sigma > max_sigma) {
                     max_sigma = sigma;
                     max_val = i;

@@ -56,6 +56,7 @@ struct SegArgs {
     uint32_t cap_cdesc, cap_pool;   // per plane
     uint32_t* trig_cnt;             // per-plane counter lines (TC_CDESC, TC_POOL)
     int min_contour, max_contour;
+    int seg_chunks, cyc_chunks;     // workgroups per plane of the per-node kernels (256 threads) / of the lap kernel (64 threads)
 };
 
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
@@ -69,8 +70,14 @@ __device__ __forceinline__ bool plane_of_block(int nplanes, int chunks, int* pla
     *plane = (rest / chunks) * 8 + xcd;
     return *plane < nplanes;
 }
-constexpr int SEG_CHUNKS = 16;   // 256-thread workgroups per plane in the per-node kernels
-constexpr int CYC_CHUNKS = 32;   // 64-thread workgroups per plane in the lap kernel
+// Workgroups per plane: 16 x 256 threads in the per-node kernels and 32 x 64 in the lap kernel when a batch of planes fills the chip. A single
+// frame (the reference's call shape: one detect() per frame) has a few thousand waypoints and nothing else to run: with 16 workgroups every
+// thread looped over several waypoints one after the other (segment_kernel 119 us of a 440 us call, round 3); it gets enough workgroups that
+// every waypoint has a lane of its own.
+static void seg_chunks_for(int nplanes, int* seg, int* cyc) {
+    *seg = nplanes <= 2 ? 128 : nplanes <= 8 ? 48 : 16;
+    *cyc = nplanes <= 2 ? 256 : nplanes <= 8 ? 96 : 32;
+}
 
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, uint32_t mask) { return (key * 2654435761u >> 7) & mask; }
 
@@ -111,7 +118,7 @@ __device__ __forceinline__ bool is_waypoint(const uint64_t* tiles, int tnx, uint
 __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
     __shared__ uint32_t rows[TB_ROWS * 256];
     int plane, chunk;
-    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
     const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     const size_t nb = (size_t)plane * a.cap_raw;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
     const int tid = threadIdx.x;
     // a border that avoids the grid is confined to one S x S cell: at most 4 visits per pixel
     const int max_steps = 4 * (a.grid_mask + 1) * (a.grid_mask + 1) + 8;
-    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += SEG_CHUNKS * blockDim.x) {
+    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += a.seg_chunks * blockDim.x) {
         const uint32_t i = i0 + tid;
         bool live = i < n;
         const uint2 rec = live ? a.raw[nb + i] : make_uint2(0u, (0x00010001u << 2) | 2u);
@@ -187,11 +194,11 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
 // Kernel S3: next key -> node index
 __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
     int plane, chunk;
-    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
     const size_t nb = (size_t)plane * a.cap_raw;
     const uint32_t* hash = a.hash + (size_t)plane * (a.hash_mask + 1);
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += SEG_CHUNKS * blockDim.x) {
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += a.seg_chunks * blockDim.x) {
         const uint4 nd = a.node[nb + i];
         const uint32_t key = nd.x;
         uint32_t found = i;   // a dead node points at itself
@@ -220,10 +227,10 @@ __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
 // node whose segment holds a smaller key and can only leave larger stamps behind.
 __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
     int plane, chunk;
-    if (!plane_of_block(a.nplanes, CYC_CHUNKS, &plane, &chunk)) return;
+    if (!plane_of_block(a.nplanes, a.cyc_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
     const size_t nb = (size_t)plane * a.cap_raw;
-    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += CYC_CHUNKS * blockDim.x) {
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += a.cyc_chunks * blockDim.x) {
         if ((a.node[nb + i].z >> 16) != 1u) continue;
         const uint32_t key = a.raw[nb + i].y, pos0 = key >> 2;
         const int hole = (key & 3u) == 0;
@@ -274,12 +281,12 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
 __global__ __launch_bounds__(256) void emit_kernel(SegArgs a) {
     __shared__ uint32_t rows[TB_ROWS * 256];
     int plane, chunk;
-    if (!plane_of_block(a.nplanes, SEG_CHUNKS, &plane, &chunk)) return;
+    if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
     const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * a.tnx * a.tny;
     const size_t nb = (size_t)plane * a.cap_raw;
     const int tid = threadIdx.x;
-    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += SEG_CHUNKS * blockDim.x) {
+    for (uint32_t i0 = chunk * blockDim.x; i0 < n; i0 += a.seg_chunks * blockDim.x) {
         const uint32_t i = i0 + tid;
         bool live = i < n;
         unsigned long long st = NONE64;
@@ -329,16 +336,17 @@ static void fill_seg_args(SegArgs& a, const FrameGeom& g, int nplanes, const Det
     a.hash = b.hash, a.hash_mask = b.hash_mask;
     a.cdesc = b.cdesc, a.pool = b.pool, a.counters = b.counters, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool, a.trig_cnt = b.trig_cnt;
     a.min_contour = p.min_contour, a.max_contour = p.max_contour;
+    seg_chunks_for(nplanes, &a.seg_chunks, &a.cyc_chunks);
 }
 
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
     SegArgs a;
     fill_seg_args(a, g, nplanes, p, b);
     const int groups = (nplanes + 7) / 8 * 8;
-    hipLaunchKernelGGL(segment_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(link_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(cycle_kernel, dim3(groups * CYC_CHUNKS), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(emit_kernel, dim3(groups * SEG_CHUNKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(segment_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(link_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cycle_kernel, dim3(groups * a.cyc_chunks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(emit_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
 }
 
 }  // namespace ah

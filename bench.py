@@ -616,7 +616,7 @@ def main():
         ktimes_iso = handle.kernel_times()
         iso_exec_ms, iso_exec_n = handle.threshold_exec_ms()
         handle.enable_timing(False)
-    fill = handle.debug_counters() if args.clutter else None
+    fill = handle.debug_counters() if (args.clutter or "WALK_STATS" in build) else None
 
     if rank == 0:
         total_frames = world * B * args.steps

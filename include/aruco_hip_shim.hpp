@@ -579,7 +579,8 @@ public:
         float K[9], d[8];
         bool hasK = mat_to_K_(camMatrix, K);
         int nd = mat_to_dist_(distCoeff, d);
-        std::vector<arucohip_marker_t> out(256);
+        std::vector<arucohip_marker_t>& out = out_;   // the detector's own result buffer: a frame loop allocates nothing per call
+        if (out.size() < 256) out.resize(256);
         int n = 0, rc;
         for (int attempt = 0;; attempt++) {
             rc = input.type() == CV_8UC3
@@ -814,6 +815,7 @@ private:
         return id;
     }
     MarkerdetectorFunc user_fn_ = nullptr;
+    std::vector<arucohip_marker_t> out_;
     arucohip_handle* h_;
     int device_, cap_w_, cap_h_;
     int grow_ = 0;   // doublings of the device list limits after overflows

@@ -86,3 +86,58 @@ def test_shim_refine_candidate_lines(tmp_path):
         seen += 1
     assert seen == len(gold)
     assert "isYPerpendicular 0 1" in r.stdout
+
+
+@pytest.mark.parametrize("case", ["single", "board", "chessboard", "hrm", "synthetic_1080p"])
+def test_single_frame_graph_path_returns_the_bytes_of_the_eager_path(case, monkeypatch):
+    """arucohip_detect on one host frame (the reference's call shape, test/perf_tests.cpp:31-56): from the second call of a configuration on
+    the ~20 dispatches of a frame are replayed from a captured hipGraph. Eager handle (ARUCOHIP_GRAPH=0 at creation) against the default
+    handle, three calls each (eager, capture + launch, replay), on the reference's four stills and one 1080p bench frame (walkers with the
+    fork to the side stream): identical bytes every time - and again after the parameters change (a new graph) and change back."""
+    from aruco_amd import capi, synth
+
+    K = dist = None
+    msize = -1.0
+    p = capi.default_params()
+    dic = None
+    if case == "synthetic_1080p":
+        fr, _ = synth.make_stream(2, seed=4711, device="cpu")
+        gray, other = fr[0].numpy(), fr[1].numpy()
+    else:
+        gray, doc = load_case(case)
+        other = np.ascontiguousarray(gray[:, ::-1])
+        K, dist, msize = doc["intrinsics"]["K"], doc["intrinsics"]["dist"], 1.0
+        if case == "hrm":
+            st, dic = doc["settings"], doc["dictionary"]
+            p.thres_param1, p.thres_param2, p.min_size, p.max_size, p.warp_size = st["thres_param1"], st["thres_param2"], st["min_size"], st["max_size"], st["warp_size"]
+            msize = st["marker_size"]
+    hgt, wid = gray.shape
+    monkeypatch.setenv("ARUCOHIP_GRAPH", "0")
+    eager = capi.Handle(wid, hgt, max_batch=1, params=p)
+    monkeypatch.delenv("ARUCOHIP_GRAPH")
+    graphed = capi.Handle(wid, hgt, max_batch=1, params=p)
+    try:
+        if dic:
+            eager.set_dictionary(dic["markers"], dic["tau0"])
+            graphed.set_dictionary(dic["markers"], dic["tau0"])
+        ref = eager.detect(gray, K=K, dist=dist, marker_size=msize)
+        ref_other = eager.detect(other, K=K, dist=dist, marker_size=msize)
+        assert len(ref) >= 6
+        for _ in range(3):
+            assert graphed.detect(gray, K=K, dist=dist, marker_size=msize).tobytes() == ref.tobytes()
+        assert graphed.detect(other, K=K, dist=dist, marker_size=msize).tobytes() == ref_other.tobytes()     # another frame through the same graph
+        assert graphed.thresholded(0, (hgt, wid)).tobytes() == eager.thresholded(0, (hgt, wid)).tobytes()  # getters address the graphed call
+        q = graphed.get_params()
+        q.corner_method = capi.CORNER_SUBPIX
+        graphed.set_params(q), eager.set_params(q)
+        ref2 = eager.detect(gray, K=K, dist=dist, marker_size=msize)
+        for _ in range(3):
+            assert graphed.detect(gray, K=K, dist=dist, marker_size=msize).tobytes() == ref2.tobytes()
+        q.corner_method = capi.CORNER_LINES
+        graphed.set_params(q)
+        for _ in range(3):
+            assert graphed.detect(gray, K=K, dist=dist, marker_size=msize).tobytes() == ref.tobytes()
+        # without a camera: another configuration again
+        assert graphed.detect(gray).tobytes() == graphed.detect(gray).tobytes() == graphed.detect(gray).tobytes()
+    finally:
+        eager.close(), graphed.close()

@@ -304,3 +304,89 @@ def test_canny_against_numpy_and_connected_components():
         seeds = np.unique(lab[surv & (c > 220)])
         exp = np.where(np.isin(lab, seeds[seeds > 0]), 255, 0).astype(np.uint8)
         assert np.array_equal(orc.canny(g), exp)
+
+
+def test_otsu_sweep_with_skipped_empty_runs_is_bit_identical():
+    """The device's Otsu sweep (aruco_amd/csrc/k_decode.hip: otsu_kernel) skips runs of empty histogram bins once fl(fl(mu1 * q1) / q1) leaves
+    mu1 unchanged, and stops behind the last occupied bin. A Python model of exactly that control flow (IEEE doubles, the same operations in
+    the same order) against the plain 256-step sweep the oracle restates (cv::threshold OTSU): same threshold AND the same final (mu1, q1,
+    max_sigma) on 3000 histograms - bimodal patches like a marker's, flat ones, single-level ones, sparse ones."""
+    import numpy as np
+    EPS = float(np.finfo(np.float32).eps)
+
+    def plain(hist, n):
+        scale, mu = 1.0 / n, sum(i * float(h) for i, h in enumerate(hist)) * (1.0 / n)
+        mu1 = q1 = max_sigma = max_val = 0.0
+        for i in range(256):
+            p = float(hist[i]) * scale
+            mu1 *= q1
+            q1 += p
+            q2 = 1.0 - q1
+            if min(q1, q2) < EPS or max(q1, q2) > 1.0 - EPS:
+                continue
+            mu1 = (mu1 + i * p) / q1
+            mu2 = (mu - q1 * mu1) / q2
+            sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+            if sigma > max_sigma:
+                max_sigma, max_val = sigma, float(i)
+        return int(max_val), max_sigma
+
+    def skipping(hist, n):
+        scale, mu = 1.0 / n, sum(i * float(h) for i, h in enumerate(hist)) * (1.0 / n)
+        mu1 = q1 = max_sigma = max_val = 0.0
+        steps = 0
+        i = 0
+        while i < 256:
+            empty = hist[i] == 0
+            stage_end = (i // 64 + 1) * 64                     # the kernel stages 64 bins at a time; a run is cut at the stage boundary
+            run_end = i + 1
+            if empty:
+                run_end = i
+                while run_end < stage_end and hist[run_end] == 0:
+                    run_end += 1
+            p = 0.0 if empty else float(hist[i]) * scale
+            mu1_in = mu1
+            mu1 *= q1
+            q1 += p
+            q2 = 1.0 - q1
+            cur = i
+            i += 1
+            steps += 1
+            if min(q1, q2) < EPS or max(q1, q2) > 1.0 - EPS:
+                if q1 > 0.5:
+                    break
+                if empty:
+                    i = run_end
+                continue
+            mu1 = (mu1 + cur * p) / q1
+            if empty and mu1 == mu1_in:
+                i = run_end
+                continue
+            mu2 = (mu - q1 * mu1) / q2
+            sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+            if sigma > max_sigma:
+                max_sigma, max_val = sigma, float(cur)
+        return int(max_val), max_sigma, steps
+
+    rng = np.random.RandomState(12)
+    total_steps = 0
+    for k in range(3000):
+        n = 56 * 56 if k % 3 else 28 * 28
+        kind = k % 5
+        if kind == 0:      # a marker patch: two clusters a few levels wide
+            a, b = rng.randint(5, 120), rng.randint(130, 250)
+            v = np.where(rng.rand(n) < rng.uniform(0.2, 0.8), rng.normal(a, rng.uniform(0.5, 4), n), rng.normal(b, rng.uniform(0.5, 6), n))
+        elif kind == 1:    # smooth ramp
+            v = rng.uniform(rng.randint(0, 100), rng.randint(120, 255), n)
+        elif kind == 2:    # one or two exact levels
+            v = np.where(rng.rand(n) < rng.uniform(0, 1), rng.randint(0, 256), rng.randint(0, 256))
+        elif kind == 3:    # sparse levels with long empty runs
+            v = rng.choice(rng.randint(0, 256, size=rng.randint(2, 9)), n)
+        else:              # extremes 0 / 255 plus noise
+            v = np.where(rng.rand(n) < 0.5, 0, 255) + (rng.rand(n) < 0.1) * rng.randint(-3, 4, n)
+        hist = np.bincount(np.clip(np.rint(v), 0, 255).astype(np.int64), minlength=256)
+        t0, s0 = plain(hist, n)
+        t1, s1, steps = skipping(hist, n)
+        assert (t0, s0) == (t1, s1), k
+        total_steps += steps
+    assert total_steps < 0.6 * 3000 * 256      # and the skipping is real
