@@ -128,7 +128,8 @@ def test_single_frame_graph_path_returns_the_bytes_of_the_eager_path(case, monke
         assert graphed.detect(other, K=K, dist=dist, marker_size=msize).tobytes() == ref_other.tobytes()     # another frame through the same graph
         assert graphed.thresholded(0, (hgt, wid)).tobytes() == eager.thresholded(0, (hgt, wid)).tobytes()  # getters address the graphed call
         q = graphed.get_params()
-        q.corner_method = capi.CORNER_SUBPIX
+        # another configuration = another graph (the HRM settings' threshold block of 21 is above the SUBPIX window limit: CORNER_NONE there)
+        q.corner_method = capi.CORNER_NONE if case == "hrm" else capi.CORNER_SUBPIX
         graphed.set_params(q), eager.set_params(q)
         ref2 = eager.detect(gray, K=K, dist=dist, marker_size=msize)
         for _ in range(3):
