@@ -61,7 +61,7 @@ SYMBOLS = [
     "arucohip_destroy", "arucohip_set_params", "arucohip_get_params", "arucohip_last_error_string", "arucohip_set_stream",
     "arucohip_get_stream", "arucohip_synchronize", "arucohip_detect", "arucohip_detect_batch", "arucohip_batch_status", "arucohip_batch_chunks",
     "arucohip_get_thresholded", "arucohip_get_candidates", "arucohip_threshold", "arucohip_detect_rectangles",
-    "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates",
+    "arucohip_warp", "arucohip_debug_num_contours", "arucohip_debug_contour", "arucohip_debug_candidates", "arucohip_debug_otsu",
     "arucohip_board_detect", "arucohip_calculate_extrinsics", "arucohip_stage_times", "arucohip_stage_name",
     "arucohip_enable_timing", "arucohip_kernel_times", "arucohip_threshold_exec_ms", "arucohip_kernel_name",
     "arucohip_debug_counters", "arucohip_board_detect_batch",
@@ -458,6 +458,13 @@ class Handle:
         k = n.value
         return q[:k].copy(), ids[:k].copy(), nrot[:k].copy()
 
+    def debug_otsu(self, frame=0, cap=512):
+        """Otsu threshold of every candidate's patch (candidate order of debug_candidates)."""
+        t = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.arucohip_debug_otsu(self.h, frame, _ptr(t), cap, C.byref(n)))
+        return t[:n.value].copy()
+
     def debug_contours(self, frame=0):
         n = C.c_int(0)
         self._chk(self.L.arucohip_debug_num_contours(self.h, frame, C.byref(n)))
@@ -538,8 +545,7 @@ class Handle:
         c = np.zeros(8, np.uint32)
         self._chk(self.L.arucohip_debug_counters(self.h, _ptr(c)))
         return {"raw": int(c[4]), "triggers": int(c[0]), "contours": int(c[1]), "points": int(c[2]), "status": int(c[3]),
-                # walker mode: [4] = long walks (checkpoint rings handed out); a -DWALK_STATS variant build also counts the border steps
-                "long_walks": int(c[4]), "first_pass_steps": int(c[5]), "generation_steps": int(c[6]), "generation_lane_slots": int(c[7])}
+                "long_walks": int(c[4])}   # walker mode: [4] = long walks (checkpoint rings handed out)
 
     def gl_modelview_batch(self, nframes, cap=64):
         """Marker::glGetModelViewMatrix for every marker of the last batch (device kernel): list per frame of [n][16]."""

@@ -34,8 +34,8 @@ Tuning read_tuning() {
     t.cand_chunks = std::max(1, geti("ARUCOHIP_CAND_CHUNKS", 16));
     t.leash = geti("ARUCOHIP_LEASH", 0);
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
-    t.pull_q = geti("ARUCOHIP_PULL_Q", 1);
-    t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 24));
+    t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 12));
+    t.quad_dual = geti("ARUCOHIP_QUAD_DUAL", 1) != 0;
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
 #ifdef ARUCOHIP_STAGE_EXPERIMENT
@@ -379,9 +379,10 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     {
         // contour pipeline: ARUCOHIP_CONTOURS = walkers | segments; default by handle shape. The per-candidate walkers win on
         // batches; a single small frame is a chain of up to max-contour dependent border steps for them, which the waypoint
-        // segments cut (bench.py latency leg, 1000 calls: 640x480 stills 0.67-0.72 ms vs 0.49-0.52 ms; 1080p 0.89 vs 0.91)
+        // segments cut (bench.py latency leg, 1000 calls: 640x480 stills 0.67-0.72 ms vs 0.49-0.52 ms; one 1080p frame 0.80 vs 0.51 since round 4:
+        // per-plane workgroup counts scaled for one frame, the run rule read from the lane's block)
         const char* mode = getenv("ARUCOHIP_CONTOURS");
-        b.seg_mode = mode ? std::string(mode) == "segments" : (lim->max_batch == 1 && (long)lim->max_width * lim->max_height <= 1024L * 768L);
+        b.seg_mode = mode ? std::string(mode) == "segments" : (lim->max_batch == 1 && (long)lim->max_width * lim->max_height <= 2048L * 1536L);
         const char* gs = getenv("ARUCOHIP_GRID");
         int grid = gs ? atoi(gs) : 16;
         if (grid != 1 && grid != 2 && grid != 4 && grid != 8 && grid != 16 && grid != 32) grid = 8;
@@ -520,7 +521,8 @@ int arucohip_wait_event(arucohip_handle* h, void* ev) {
 
 int arucohip_enable_timing(arucohip_handle* h, int on) {
     if (!h) return ARUCOHIP_E_INVALID;
-    h->timing = on != 0;
+    h->timing = on == 1;      // on == 2: only the threshold kernel's device-clock stamps, no hipEvents between the kernels (the launches then overlap
+                              // with the other batches exactly as in an uninstrumented run: bench.py's replica pass)
     h->tsets = 0;
     for (auto* k : h->kids) k->timing = h->timing, k->tsets = 0;
     // device-clock stamps of the wide threshold kernel (k_threshold.hip): taken while timing is on, accumulators restart with it
@@ -1344,6 +1346,33 @@ int arucohip_get_candidates(arucohip_handle* h, int frame, float* quads, int cap
     return k > cap ? ARUCOHIP_E_CAPACITY : ARUCOHIP_OK;
 }
 
+// Otsu threshold of every candidate of a frame (candidate order of arucohip_debug_candidates): what otsu_kernel left in the flat list's threshold slots
+int arucohip_debug_otsu(arucohip_handle* h0, int frame, int32_t* thr, int cap, int* n) {
+    if (!h0 || frame < 0 || !thr || !n) return ARUCOHIP_E_INVALID;
+    h0 = active(h0);
+    arucohip_handle* h = route(h0, frame, &frame);
+    if (frame >= h->last_frames) return ARUCOHIP_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    uint32_t cnt[CNT_FIXED];
+    int32_t nc = 0;
+    HIPCHK(h, hipMemcpyAsync(cnt, h->buf.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&nc, h->buf.ncands + frame, sizeof(nc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t nflat = std::min(cnt[CNT_NCAND], h->buf.cap_flat);
+    std::vector<uint32_t> list(nflat);
+    std::vector<int32_t> othr(nflat);
+    if (nflat) {
+        HIPCHK(h, hipMemcpyAsync(list.data(), h->buf.cand_list, nflat * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(othr.data(), h->buf.othr, nflat * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    *n = std::max(nc, 0);
+    for (int i = 0; i < std::min(*n, cap); i++) thr[i] = -1;
+    for (uint32_t i = 0; i < nflat; i++)
+        if ((int)(list[i] >> 16) == frame && (int)(list[i] & 0xFFFFu) < cap) thr[list[i] & 0xFFFFu] = othr[i];
+    return *n > cap ? ARUCOHIP_E_CAPACITY : ARUCOHIP_OK;
+}
+
 int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int32_t* ids, int32_t* nrot, int cap, int* n) {
     std::vector<Cand> v;
     int rc = fetch_cands(h, frame, &v);
@@ -1426,7 +1455,7 @@ int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
     h = active(h);
     HIPCHK(h, hipSetDevice(h->device));
     uint64_t acc[CNT_FIXED] = {};
-    uint64_t ntrig = 0, nraw = 0, nlong = 0, first_steps = 0;
+    uint64_t ntrig = 0, nraw = 0, nlong = 0;
     for (int c = 0; c < std::max(h->last_chunks, 1); c++) {
         arucohip_handle* w = c == 0 ? h : h->kids[c - 1];
         uint32_t cnt[CNT_FIXED];
@@ -1445,12 +1474,10 @@ int arucohip_debug_counters(arucohip_handle* h, uint32_t* out8) {
             nraw += rc_[(size_t)p * TRIG_CNT_STRIDE];
             nlong += rg[(size_t)p * TRIG_CNT_STRIDE] + rg[(size_t)p * TRIG_CNT_STRIDE + 1];
         }
-        first_steps += cnt[CNT_STAT_FIRST];
     }
     for (int i = 0; i < CNT_FIXED; i++) out8[i] = (uint32_t)std::min<uint64_t>(acc[i], 0xFFFFFFFFu);
     out8[0] = (uint32_t)std::min<uint64_t>(ntrig, 0xFFFFFFFFu);   // start candidates after the run rule (all planes)
     out8[4] = (uint32_t)std::min<uint64_t>(h->buf.seg_mode ? nraw : nlong, 0xFFFFFFFFu);   // waypoint records (segment mode) / long walks = checkpoint rings handed out
-    out8[5] = (uint32_t)std::min<uint64_t>(first_steps, 0xFFFFFFFFu);   // -DWALK_STATS variant: border steps of the first walker pass (else 0); [6], [7]: see internal.h
     return ARUCOHIP_OK;
 }
 

@@ -33,9 +33,6 @@ enum Counter {
     CNT_UNUSED2 = 2,
     CNT_STATUS = 3,    // overflow bit flags
     CNT_NCAND = 5,     // entries of the flat candidate list (all frames)
-    CNT_STAT_STEPS = 6,   // -DWALK_STATS variant builds only: border steps the walker generations took (all planes)
-    CNT_STAT_SLOTS = 7,   //   lane-step slots their waves spent (wave iterations x CHUNK x 64): steps / slots = lane utilisation
-    CNT_STAT_FIRST = 1,   //   border steps of the first walker pass
     CNT_FIXED = 8      // per-frame counters follow: [CNT_FIXED + f] = quads of frame f
 };
 
@@ -129,10 +126,10 @@ struct Tuning {
     int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
     int ngens = 0;
     int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
-    int pull_q = 1;            // ARUCOHIP_PULL_Q: a generation wave owns 64 * pull_q walks and its lanes take the next one when theirs ends. Measured (round 4,
-                               // profiles/r04_walker_steps.txt): 2 / 4 raise the lane utilisation of the generations from 60 % to 69 % / 80 % and LOSE 4 % / 9 % of
-                               // the frame rate - the generations are bound by the latency of a wave iteration with every wave resident, not by lane-step slots; 1 stays
-    int quad_blocks = 24;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad (8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72)
+    int quad_dual = 1;         // ARUCOHIP_QUAD_DUAL=0: one border per wave in contour_quad (round 3), 1: two borders of <= 512 points per wave
+    int quad_blocks = 12;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad. One border per wave (rounds 1-3): 8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72 -> 24.
+                               // Two borders per wave (round 4): a workgroup needs an even number of short borders to pair them all, so fewer, longer lists:
+                               // 24 / 16 / 12 = 467.7k / 471.1k / 480.0k frames/s (flat stream), 273.1k / 276.2k / 276.2k (cluttered), same box
     int thres_lazy = 1;        // ARUCOHIP_THRES_BYTES=1 clears it: the threshold kernel always writes the byte image
     int threshold_wide = 1;    // ARUCOHIP_THRESHOLD_WIDE: 16-pixel-per-lane threshold kernel where it applies
 #ifdef ARUCOHIP_STAGE_EXPERIMENT

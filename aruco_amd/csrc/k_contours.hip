@@ -458,7 +458,6 @@ struct WalkArgs {
     int leash;             // steps every candidate gets in the first pass
     int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
     int gen_blocks;        // 64-lane workgroups per kind in this launch (each loops over its share of the list)
-    int pull_q;            // a wave's slice of the list is 64 * pull_q entries: its lanes take the slice's next entry when their walk ends
     uint32_t long_cap;     // rings per plane and kind
     uint32_t* ring_cnt;   // per plane line: rings handed out (outer, hole)
     uint32_t* scratch;     // [P][2][long_cap][maxck] checkpoint ring of every long walk
@@ -698,13 +697,6 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
         int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s,
                                      [&](uint32_t q) { return ck0 + q * 64 + lane; }, &blk);
         if (!live) res = WR_BAD;
-#ifdef WALK_STATS
-        {
-            uint32_t st = live ? n : 0u;
-            for (int o = 32; o > 0; o >>= 1) st += __shfl_xor(st, o, 64);
-            if (lane == 0) atomicAdd(&a.counters[CNT_STAT_FIRST], st);
-        }
-#endif
         // ---- walks that outlast the leash join generation 1 with their state; their checkpoints move to a ring in HBM
         {
             bool longw = live && res == WR_LIMIT && n < nmax;
@@ -762,14 +754,12 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
 }
 
 // Kernel 2b, one launch per generation: the walks that are still open after the previous generation, from all planes, as
-// one dense list per kind; survivors (with their state) are appended to the next generation's list.
-// Round 4: a wave owns a SLICE of 64 * pull_q consecutive list entries and every lane whose walk has ended takes the slice's next entry (taking
-// over a walk costs what a re-centring costs - the block load it needs anyway -, no atomics are involved, and which lane follows which border
-// changes nothing in the results). With pull_q = 1 this is round 3's "64 walks per wave". Measured on the bench stream with a -DWALK_STATS build
-// (profiles/r04_walker_steps.txt): per frame 20.4 k border steps in the first pass and 65.1 k in the generations; the generations' waves spend
-// 108 k lane-step slots on them with pull_q = 1 (60 % of the lanes busy), 95 k with 2, 82 k with 4 - and run 0.64 / 0.84 / 1.07 ms: fewer, fuller
-// waves are SLOWER. Every generation wave is resident at once, so the time is the number of iterations of the longest walk times the latency of an
-// iteration (a block load from HBM under load plus eight dependent steps), not the lane-step slots. pull_q stays 1; the knob is kept.
+// one dense list per kind. Every wave takes 64 of them, walks at most gen_steps steps and appends the survivors (with
+// their state) to the next generation's list, so wavefronts are full apart from the walks that end inside a generation;
+// the generations grow from 64 steps (many walks alive) to thousands (a handful of very long borders).
+// Round 4 measured the alternative "a wave owns 64 q walks and its lanes take over the next one when theirs ends" (lane utilisation of the generations
+// 60 % -> 69 % / 80 % for q = 2 / 4, and the stage 0.64 -> 0.84 / 1.07 ms: every generation wave is resident at once, the time is the iterations of the
+// longest walk times the latency of an iteration, not lane-step slots). Step counts and the A/B: profiles/r04_walker_steps.txt. Not kept.
 template <bool HOLE>
 __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, uint32_t* rows) {
     const int kind = HOLE ? 1 : 0, lane = threadIdx.x;
@@ -777,94 +767,34 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
     const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap, dst = ((size_t)kind * 2 + ((a.gen + 1) & 1)) * a.gen_cap;
     const uint32_t nmax = (uint32_t)a.max_contour;
     const size_t plane_tiles = (size_t)a.tnx * a.tny;
-    const int maxbx = (a.tnx - 4) * 8, maxby = (a.tny - 4) * 8;
-    const uint32_t slice = 64u * (uint32_t)a.pull_q;
-    const uint32_t* rb = rows + lane - 64;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t first = (uint32_t)chunk * slice; first < count; first += (uint32_t)a.gen_blocks * slice) {
-        const uint32_t end = min(first + slice, count);
-        uint32_t next = first;   // wave-uniform: the slice's next entry nobody has taken
-        // the lane's walk (valid while `walking`)
-        bool walking = false, was_bad = false, was_closed = false;
-        uint32_t tkey = 0, pos0 = 0, pos1 = 0, n = 0, lim = 0, ring = 0, lp = 0, s1c = TB_S1C, base1 = 0, p0b = 0, p1b = 0, tkb = 0;
-        int plane = 0;
-        const uint64_t* __restrict__ tiles = a.tiles;
-        uint32_t* ck = a.scratch;
-        TileBlock blk;
-        blk.bx = blk.by = 0;
-#ifdef WALK_STATS   // variant build only (tools/build_variant.sh walkstats -DWALK_STATS): border steps walked and lane-step slots spent by the generations
-        uint32_t st_steps = 0, st_iters = 0;
-#endif
-        for (;;) {
-            // ---- idle lanes take the next entries of the slice
-            bool fresh = false;
-            {
-                const unsigned long long idle = __ballot(!walking);
-                if (idle && next < end) {
-                    const uint32_t idx = next + (uint32_t)__popcll(idle & below);
-                    if (!walking && idx < end) {
-                        const uint4 st = a.gen_state[src + idx];
-                        ring = a.gen_ring[src + idx];
-                        tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
-                        n = st.w & 0xFFFFu, s1c = tb_s1c((int)(st.w >> 16));
-                        plane = (int)(ring / (2u * a.long_cap));
-                        tiles = a.tiles + (size_t)plane * plane_tiles;
-                        ck = a.scratch + (size_t)ring * a.maxck;
-                        lim = min(n + (uint32_t)a.gen_steps, nmax);
-                        base1 = 0, lp = st.y;   // the position as it is until the block is placed
-                        walking = n < lim, fresh = true, was_bad = false, was_closed = false;
-                    }
-                    next = min(end, next + (uint32_t)__popcll(idle));
-                }
-            }
-            if (!__any(walking)) break;
-            const bool had = walking;
-            {
-                // a side that is clamped to the image needs no margin: the border cannot leave the image
-                const int lxm = (int)(lp & 0xFFFFu), ly = (int)(lp >> 16);   // lxm = x - bx - 1
-                const bool near = (lxm < CHUNK && blk.bx > 0) || (lxm > 29 - CHUNK && blk.bx < maxbx) || (ly < 1 + CHUNK && blk.by > 0) || (ly > 30 - CHUNK && blk.by < maxby);
-                const uint32_t at = lp + base1;
-                {
-                    // a closed border that reaches Chebyshev distance d from its start has at least 2 d points (walk_run)
-                    const int ax = abs((int)(at & 0xFFFFu) - (int)(pos0 & 0xFFFFu)), ay = abs((int)(at >> 16) - (int)(pos0 >> 16));
-                    if (walking && 2u * (uint32_t)max(ax, ay) >= nmax) walking = false, was_bad = true;
-                }
-                if (walking && (near || fresh)) {
-                    tb_load_dir<64, CHUNK>(tiles, a.tnx, a.tny, at, tb_s_of(s1c), rows, lane, blk);
-                    base1 = tb_base1(blk), lp = at - base1;
-                    p0b = pos0 - base1, p1b = pos1 - base1, tkb = tkey - base1;
-                }
-            }
-#ifdef WALK_STATS
-            const uint32_t n_before = n;
-#endif
-            walk_chunk<HOLE, 64>(rb, base1, p0b, p1b, tkb, pos0, lim, lp, s1c, n, walking, was_bad, was_closed, [&](uint32_t q) { return ck + q; });
-#ifdef WALK_STATS
-            st_steps += had ? n - n_before : 0u, st_iters++;
-#endif
-            // ---- walks that ended in this chunk: a closed border inside the size filter is kept, a walk at its limit goes on in the next generation
-            const bool ended = had && !walking;
-            if (ended && !was_bad && was_closed && n < nmax && (int)n > a.min_contour) {
-                uint32_t at_;
-                keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at_);
-            }
-            const bool again = ended && !was_bad && !was_closed && n < nmax;
-            const unsigned long long bal = __ballot(again);
-            if (bal) {
-                uint32_t at0 = 0;
-                if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
-                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
-                if (again) {
-                    const size_t li = dst + at0 + (uint32_t)__popcll(bal & below);   // at most as many entries as this list had
-                    a.gen_state[li] = make_uint4(tkey, lp + base1, pos1, n | ((uint32_t)tb_s_of(s1c) << 16));
-                    a.gen_ring[li] = ring;
-                }
+    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += (uint32_t)a.gen_blocks * 64u) {
+        const bool live = base + lane < count;
+        const uint4 st = live ? a.gen_state[src + base + lane] : make_uint4(0x00200021u, 0x00200020u, 0u, 0u);
+        const uint32_t ring = live ? a.gen_ring[src + base + lane] : 0u;
+        const uint32_t tkey = st.x, pos1 = st.z, pos0 = tkey - (HOLE ? 1u : 0u);
+        uint32_t pos = st.y, n = st.w & 0xFFFFu;
+        int s = (int)(st.w >> 16);
+        const int plane = (int)(ring / (2u * a.long_cap));
+        const uint64_t* __restrict__ tiles = a.tiles + (size_t)plane * plane_tiles;
+        uint32_t* ck = a.scratch + (size_t)ring * a.maxck;
+        const uint32_t lim = min(n + (uint32_t)a.gen_steps, nmax);
+        const int res = walk_run<HOLE, 64>(tiles, a.tnx, a.tny, rows, lane, live, tkey, pos0, pos1, lim, nmax, pos, n, s, [&](uint32_t q) { return ck + q; });
+        if (live && res == WR_CLOSED && n < nmax && (int)n > a.min_contour) {
+            uint32_t at;
+            keep_border(a, plane, HOLE, tkey, pos0, n, 0u, (uint32_t)((size_t)ring * a.maxck), &at);
+        }
+        const bool again = live && res == WR_LIMIT && n < nmax;
+        const unsigned long long bal = __ballot(again);
+        if (bal) {
+            uint32_t at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+            at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+            if (again) {
+                const size_t li = dst + at0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));   // at most as many entries as this list had
+                a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
+                a.gen_ring[li] = ring;
             }
         }
-#ifdef WALK_STATS
-        for (int o = 32; o > 0; o >>= 1) st_steps += __shfl_xor(st_steps, o, 64);
-        if (lane == 0) atomicAdd(&a.counters[CNT_STAT_STEPS], st_steps), atomicAdd(&a.counters[CNT_STAT_SLOTS], st_iters * (uint32_t)(CHUNK * 64));
-#endif
     }
 }
 
@@ -947,8 +877,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
         // plane's ~1000 candidates reach generation 1), fewer for the thin late generations; surplus workgroups exit at once
         const int before = done - a.gen_steps;   // steps every walk of this generation has behind it
         const int per_plane_x16 = before < 200 ? 64 : before < 450 ? 40 : before < 1100 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
-        a.pull_q = std::max(1, std::min(16, b.tune.pull_q));
-        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2 / a.pull_q));
+        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2));
         hipLaunchKernelGGL(walker_long_kernel, dim3(2 * a.gen_blocks), dim3(64), 0, cur, a);
     }
     if (forked) (void)hipEventRecord(fk.joined, fk.side);
@@ -988,6 +917,33 @@ __device__ __forceinline__ void wave_argmax_first(uint32_t val, uint32_t idx, ui
     *first_idx = wave_min_u32(val == mv ? idx : 0xFFFFFFFFu);
 }
 
+// The same reductions for the two halves of a wave at once (round 4: two borders per wave, one per half): the butterfly inside the rows of 16 lanes and
+// the first row broadcast leave the maximum of lanes 0..31 in row 1 and that of lanes 32..63 in row 3; no step reads across the halves.
+#define DPP_FOLD_HALF(op, v)                                                                                    \
+    asm volatile("s_nop 4\n\t"                                                                                  \
+                 op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                            \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"             \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                 \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                      \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+                 "s_nop 1"                                                                                      \
+                 : "+v"(v))
+__device__ __forceinline__ uint32_t half_max_u32(uint32_t v, bool upper) {
+    DPP_FOLD_HALF("v_max_u32_dpp", v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v, bool upper) {
+    DPP_FOLD_HALF("v_min_u32_dpp", v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ void half_argmax_first(uint32_t val, uint32_t idx, bool upper, uint32_t* max_val, uint32_t* first_idx) {
+    const uint32_t mv = half_max_u32(val, upper);
+    *max_val = mv;
+    *first_idx = half_min_u32(val == mv ? idx : 0xFFFFFFFFu, upper);
+}
+
 // The "farthest point" scans of approxPolyDP over the cyclic index range first, first + 1, ... (len entries, first < count, len <= count) as two
 // linear runs (up to the end of the border, then from its beginning), so that no entry needs a wrap test; every lane keeps the first maximum of its
 // own entries (only a strictly greater value replaces it, its entries come in scan order), the key is the scan position. A point is one 32-bit word
@@ -1002,17 +958,17 @@ __device__ __forceinline__ uint32_t scan_value(uint32_t pt, uint32_t anchor, uin
     const int cr = __builtin_amdgcn_sdot2(d, as_s2(w), 0, false);
     return (uint32_t)max(cr, -cr);
 }
-template <bool CROSS>
+template <bool CROSS, int STRIDE = WAVE>
 __device__ __forceinline__ void scan_cyclic(const uint32_t* P32, int count, int first, int len, int lane, uint32_t anchor, uint32_t w, uint32_t& bd, uint32_t& bk) {
     bd = 0, bk = 0xFFFFFFFFu;
     const int lenA = min(len, count - first);
     const uint32_t* pa = P32 + first;
-    for (int k = lane; k < lenA; k += WAVE) {
+    for (int k = lane; k < lenA; k += STRIDE) {
         const uint32_t v = scan_value<CROSS>(pa[k], anchor, w);
         if (v > bd) bd = v, bk = (uint32_t)k;
     }
     const uint32_t* pb = P32 - lenA;
-    for (int k = lenA + lane; k < len; k += WAVE) {
+    for (int k = lenA + lane; k < len; k += STRIDE) {
         const uint32_t v = scan_value<CROSS>(pb[k], anchor, w);
         if (v > bd) bd = v, bk = (uint32_t)k;
     }
@@ -1023,7 +979,10 @@ __device__ __forceinline__ void scan_cyclic(const uint32_t* P32, int count, int 
                           // batches in flight the vector-instruction count is what counts: 446.3k / 447.6k against 443.2k / 442.5k fps, same box, alternating
 #endif
 constexpr int EMIT_LANES = EMIT_LANES_N;   // lanes that emit points at a time (each needs a 32x32 block in LDS)
-constexpr int QP_LDS = 1024;   // points of a border kept in LDS; longer borders are scanned in HBM (their pool range)
+#ifndef QP_LDS_N
+#define QP_LDS_N 1024
+#endif
+constexpr int QP_LDS = QP_LDS_N;   // points of a border kept in LDS; longer borders are scanned in HBM (their pool range)
 
 struct QuadArgs {
     const uint64_t* tiles;
@@ -1040,7 +999,76 @@ struct QuadArgs {
     int width, height;
     int pass;
     int qblocks, nplanes;   // workgroups per plane, planes
+    int dual;               // two short borders per wave (ARUCOHIP_QUAD_DUAL, default on)
 };
+
+// The vertices approxPolyDP's recursion left (<= 8, in s_out) -> its clean-up pass, 4 vertices, cv::isContourConvex, min side -> Quad. One lane.
+__device__ __forceinline__ void polygon_to_quad(const QuadArgs& a, const ContourDesc& cd, const uint32_t ci, short2* s_out, const int outn, const double eps) {
+    int new_count = outn;
+    const int cnt = outn;
+    int p2 = cnt - 1;
+    short2 start_pt = s_out[p2];
+    if (++p2 >= cnt) p2 = 0;
+    int wpos = p2;
+    short2 pt = s_out[p2];
+    if (++p2 >= cnt) p2 = 0;
+    for (int i = 0; i < cnt && new_count > 2; i++) {
+        short2 end_pt = s_out[p2];
+        if (++p2 >= cnt) p2 = 0;
+        double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+        double dist = fabs((double)(pt.x - start_pt.x) * dy - (double)(pt.y - start_pt.y) * dx);
+        double sip = (double)(pt.x - start_pt.x) * (double)(end_pt.x - pt.x) +
+                     (double)(pt.y - start_pt.y) * (double)(end_pt.y - pt.y);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+            new_count--;
+            s_out[wpos] = start_pt = end_pt;
+            if (++wpos >= cnt) wpos = 0;
+            pt = s_out[p2];
+            if (++p2 >= cnt) p2 = 0;
+            i++;
+            continue;
+        }
+        s_out[wpos] = start_pt = pt;
+        if (++wpos >= cnt) wpos = 0;
+        pt = end_pt;
+    }
+    bool ok = new_count == 4;
+    if (ok) {  // cv::isContourConvex on 4 int points
+        short2 prev = s_out[2], cur = s_out[3];
+        int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
+        for (int i = 0; i < 4 && ok; i++) {
+            prev = cur;
+            cur = s_out[i];
+            int dx = cur.x - prev.x, dy = cur.y - prev.y;
+            int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+            orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+            if (orientation == 3) ok = false;
+            dx0 = dx, dy0 = dy;
+        }
+    }
+    if (ok) {  // minimum side > 10 px (intended form of markerdetector.cpp:542-552)
+        int mind2 = 0x7FFFFFFF;
+        for (int j = 0; j < 4; j++) {
+            int dx = s_out[j].x - s_out[(j + 1) & 3].x, dy = s_out[j].y - s_out[(j + 1) & 3].y;
+            mind2 = min(mind2, dx * dx + dy * dy);
+        }
+        ok = mind2 > 100;
+    }
+    if (ok) {
+        const int frame = cd.plane / a.nthr, t = cd.plane - frame * a.nthr;
+        uint32_t slot = atomicAdd(&a.counters[CNT_FIXED + frame], 1u);
+        if (slot < (uint32_t)a.cap_quads) {
+            Quad q;
+            for (int j = 0; j < 4; j++) q.x[j] = s_out[j].x, q.y[j] = s_out[j].y;
+            q.cdesc = (int)ci;
+            q.key = ((uint32_t)t << 26) | (0x3FFFFFFu - cd.key);
+            q.pad_ = 0;
+            a.quads[(size_t)frame * a.cap_quads + slot] = q;
+        } else {
+            flag_overflow(a.counters, a.trig_cnt, cd.plane, ST_QUAD_OVERFLOW);
+        }
+    }
+}
 
 // One border -> at most one quad. P holds the border's points: LDS (LDSP, up to QP_LDS points) or the border's own pool range.
 template <bool LDSP>
@@ -1173,82 +1201,149 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
         __syncthreads();
     }
     if (reject || outn < 4) return;
-    // ---- clean-up pass + convexity + min side, lane 0 (<= 8 vertices)
-    if (lane == 0) {
-        int new_count = outn;
-        const int cnt = outn;
-        int p2 = cnt - 1;
-        short2 start_pt = s_out[p2];
-        if (++p2 >= cnt) p2 = 0;
-        int wpos = p2;
-        short2 pt = s_out[p2];
-        if (++p2 >= cnt) p2 = 0;
-        for (int i = 0; i < cnt && new_count > 2; i++) {
-            short2 end_pt = s_out[p2];
-            if (++p2 >= cnt) p2 = 0;
-            double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
-            double dist = fabs((double)(pt.x - start_pt.x) * dy - (double)(pt.y - start_pt.y) * dx);
-            double sip = (double)(pt.x - start_pt.x) * (double)(end_pt.x - pt.x) +
-                         (double)(pt.y - start_pt.y) * (double)(end_pt.y - pt.y);
-            if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
-                new_count--;
-                s_out[wpos] = start_pt = end_pt;
-                if (++wpos >= cnt) wpos = 0;
-                pt = s_out[p2];
-                if (++p2 >= cnt) p2 = 0;
-                i++;
-                continue;
-            }
-            s_out[wpos] = start_pt = pt;
-            if (++wpos >= cnt) wpos = 0;
-            pt = end_pt;
-        }
-        bool ok = new_count == 4;
-        if (ok) {  // cv::isContourConvex on 4 int points
-            short2 prev = s_out[2], cur = s_out[3];
-            int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
-            for (int i = 0; i < 4 && ok; i++) {
-                prev = cur;
-                cur = s_out[i];
-                int dx = cur.x - prev.x, dy = cur.y - prev.y;
-                int dxdy0 = dx * dy0, dydx0 = dy * dx0;
-                orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
-                if (orientation == 3) ok = false;
-                dx0 = dx, dy0 = dy;
-            }
-        }
-        if (ok) {  // minimum side > 10 px (intended form of markerdetector.cpp:542-552)
-            int mind2 = 0x7FFFFFFF;
-            for (int j = 0; j < 4; j++) {
-                int dx = s_out[j].x - s_out[(j + 1) & 3].x, dy = s_out[j].y - s_out[(j + 1) & 3].y;
-                mind2 = min(mind2, dx * dx + dy * dy);
-            }
-            ok = mind2 > 100;
-        }
-        if (ok) {
-            const int frame = cd.plane / a.nthr, t = cd.plane - frame * a.nthr;
-            uint32_t slot = atomicAdd(&a.counters[CNT_FIXED + frame], 1u);
-            if (slot < (uint32_t)a.cap_quads) {
-                Quad q;
-                for (int j = 0; j < 4; j++) q.x[j] = s_out[j].x, q.y[j] = s_out[j].y;
-                q.cdesc = (int)ci;
-                q.key = ((uint32_t)t << 26) | (0x3FFFFFFu - cd.key);
-                q.pad_ = 0;
-                a.quads[(size_t)frame * a.cap_quads + slot] = q;
+    if (lane == 0) polygon_to_quad(a, cd, ci, s_out, outn, eps);
+}
+
+// Round 4: TWO borders per wave, one per half (lanes 0..31 / 32..63), for borders of at most DUAL_MAX points - the median kept border has 460. One
+// border per wave left half the emitting lanes idle (29 checkpoints for 64 lanes) and paid the fixed cost of every approxPolyDP iteration - stack
+// traffic, two reductions on the DPP network, the fp64 test, the barriers; about 150 instructions against 10 per 64 points scanned - per border; here
+// the two halves run the same instruction stream on their own border. Every quantity that was wave-uniform is uniform per half; `valid` is false
+// for a half without a border. Same arithmetic, same scan order, same tie breaks as border_to_quad.
+constexpr int DUAL_MAX = 512;
+__device__ __forceinline__ void border_pair_to_quads(const QuadArgs& a, const ContourDesc& cd, const uint32_t ci, const bool valid, short2* Pbase, int (*s_stack)[16][2],
+                                                     short2 (*s_out)[12], uint32_t* rows) {
+    const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
+    const bool upper = h != 0;
+    short2* P = Pbase + h * DUAL_MAX;
+    uint32_t* P32 = (uint32_t*)P;
+    const int count = valid ? cd.n : 1;
+    if (a.from_pool) {
+        if (valid)
+            for (int i = hl; i < count; i += 32) P[i] = a.pool[cd.pool_off + i];
+    } else {
+        // a lane per checkpoint (at most 32 per border): resume the walk there and record CK points from the lane's own block (border_to_quad)
+        const uint64_t* tiles = a.tiles + (size_t)cd.plane * a.tnx * a.tny;
+        const int ncp = (count + CK - 1) / CK;
+        const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
+        const uint32_t* rb = rows + lane - 64;
+        const int k = hl;
+        if (valid && k < ncp) {
+            const uint32_t c = ckp[k];
+            const uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
+            const int n0 = k * CK, n1 = min(n0 + CK, count);
+            int bx, by;   // where the stretch ends
+            if (k + 1 < ncp) {
+                const uint32_t cn = ckp[k + 1];
+                bx = (int)(cn & 0x3FFFu), by = (int)((cn >> 14) & 0x3FFFu);
             } else {
-                flag_overflow(a.counters, a.trig_cnt, cd.plane, ST_QUAD_OVERFLOW);
+                bx = cd.x0, by = cd.y0;
+            }
+            const int ax = (int)(pos & 0xFFFFu), ay = (int)(pos >> 16), L = n1 - n0;
+            const int ex = (L - abs(bx - ax)) >> 1, ey = (L - abs(by - ay)) >> 1;
+            const int tx0 = min(max((min(ax, bx) - ex - 1) >> 3, 0), a.tnx - 4), ty0 = min(max((min(ay, by) - ey - 1) >> 3, 0), a.tny - 4);
+            TileBlock blk;
+            tb_load_at<64>(tiles, a.tnx, tx0, ty0, rows, lane, blk);
+            const uint32_t base1 = tb_base1(blk);
+            uint32_t lp = pos - base1, s1c = tb_s1c((int)(c >> 28));
+#pragma unroll
+            for (int j = 0; j < CK; j++) {
+                if (n0 + j < n1) {
+                    P32[n0 + j] = lp + base1;
+                    tb_step<64>(rb, lp, s1c);
+                }
             }
         }
     }
+    __syncthreads();
+    if (!a.from_pool && valid)
+        for (int i = hl; i < count; i += 32) a.pool[cd.pool_off + i] = P[i];
+
+    // ---- cv::approxPolyDP(closed) per half
+    double eps = (double)count * 0.05;
+    eps *= eps;
+    int pos = 0, rs_start = 0;
+    bool le_eps = false;
+    const uint32_t* PW = (const uint32_t*)P;
+    for (int it = 0; it < 3; it++) {
+        pos = (pos + rs_start) % count;
+        uint32_t bd, bk, maxd, kmax;
+        scan_cyclic<false, 32>(PW, count, pos + 1 == count ? 0 : pos + 1, count - 1, hl, PW[pos], 0u, bd, bk);
+        half_argmax_first(bd, bk, upper, &maxd, &kmax);
+        if (maxd > 0) rs_start = (int)kmax + 1;
+        le_eps = (double)maxd <= eps;
+    }
+    int top = 0, outn = 0;
+    bool reject = !valid;
+    if (!le_eps) {
+        const int sl_start = pos % count;
+        const int sl_end = (rs_start + sl_start) % count;
+        if (hl == 0) {
+            s_stack[h][0][0] = sl_end, s_stack[h][0][1] = sl_start;   // right_slice
+            s_stack[h][1][0] = sl_start, s_stack[h][1][1] = sl_end;   // slice
+        }
+        top = 2;
+    } else {
+        if (hl == 0) s_out[h][0] = P[pos];
+        outn = 1;
+    }
+    __syncthreads();
+    for (;;) {
+        bool act = !reject && top > 0;
+        if (act && outn + top > 8) reject = true, act = false;   // cannot end as 4 vertices (clean-up removes at most every other vertex)
+        if (!__any(act)) break;
+        int sl_start = 0, sl_end = 0, len = 0;
+        short2 ep = make_short2(0, 0), sp = make_short2(0, 0);
+        uint32_t bd = 0, bq = 0xFFFFFFFFu;
+        int dx = 0, dy = 0;
+        if (act) {
+            --top;
+            sl_start = s_stack[h][top][0], sl_end = s_stack[h][top][1];
+            ep = P[sl_end], sp = P[sl_start];
+            len = sl_end - sl_start;
+            if (len <= 0) len += count;
+            if (len > 1) {
+                dx = ep.x - sp.x, dy = ep.y - sp.y;
+                const uint32_t w = ((uint32_t)(-dy) & 0xFFFFu) | ((uint32_t)dx << 16);
+                scan_cyclic<true, 32>(PW, count, sl_start + 1 == count ? 0 : sl_start + 1, len - 1, hl, PW[sl_start], w, bd, bq);
+            }
+        }
+        __syncthreads();
+        uint32_t maxd_u, qmax;
+        half_argmax_first(bd, bq, upper, &maxd_u, &qmax);   // every lane takes part: the DPP steps never run under a half's mask
+        if (act) {
+            bool small = true;
+            int split = 0;
+            if (len > 1) {
+                const double maxd = (double)maxd_u;
+                const int q = qmax == 0xFFFFFFFFu ? 0 : (int)qmax;
+                split = sl_start + 1 + q;
+                if (split >= count) split -= count;
+                small = maxd * maxd <= eps * ((double)dx * (double)dx + (double)dy * (double)dy);
+            }
+            if (small) {
+                if (hl == 0) s_out[h][outn] = sp;
+                outn++;
+            } else {
+                if (hl == 0) {
+                    s_stack[h][top][0] = split, s_stack[h][top][1] = sl_end;
+                    s_stack[h][top + 1][0] = sl_start, s_stack[h][top + 1][1] = split;
+                }
+                top += 2;
+            }
+        }
+        __syncthreads();
+    }
+    if (hl == 0 && !reject && outn >= 4) polygon_to_quad(a, cd, ci, s_out[h], outn, eps);
 }
 
 __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     throughput_bound_priority();
-    __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points
+    __shared__ __align__(16) short2 Plds[QP_LDS];   // contour points (two borders of up to DUAL_MAX points, or one of up to QP_LDS)
     __shared__ uint32_t rows[TB_ROWS * EMIT_LANES];  // one 32x32-pixel block per emitting lane
-    __shared__ int s_stack[16][2];
-    __shared__ short2 s_out[12];
+    __shared__ int s_stack[2][16][2];
+    __shared__ short2 s_out[2][12];
     __shared__ int s_outn;
+    static_assert(QP_LDS >= 2 * DUAL_MAX && EMIT_LANES == 64, "the two-borders-per-wave path uses the whole point buffer and a block per lane");
     // 1-D grid dealt round-robin over the 8 XCDs: all workgroups of a plane land on one XCD, whose L2 then serves the plane's tiles,
     // descriptors and checkpoints to all of them (same unpacking as walker_kernel)
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
@@ -1258,15 +1353,33 @@ __global__ __launch_bounds__(64) void contour_quad_kernel(QuadArgs a) {
     const uint32_t nall = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_CDESC], a.cap_cdesc);
     const uint32_t nsnap = min(a.trig_cnt[plane * TRIG_CNT_STRIDE + TC_SNAP], a.cap_cdesc);
     const uint32_t lo = a.pass == 2 ? nsnap : 0u, ncd = a.pass == 1 ? nsnap : nall;
+    const bool upper = threadIdx.x >= 32;
+    ContourDesc pend;   // a short border waiting for a partner
+    uint32_t pend_ci = 0;
+    bool has_pend = false;
     for (uint32_t cslot = lo + (uint32_t)chunk; cslot < ncd; cslot += (uint32_t)a.qblocks) {
         const uint32_t ci = (uint32_t)plane * a.cap_cdesc + cslot;
         const ContourDesc cd = a.cdesc[ci];
-        __syncthreads();
         if (cd.n <= 0) continue;
+        if (a.dual && cd.n <= DUAL_MAX) {
+            if (!has_pend) {
+                pend = cd, pend_ci = ci, has_pend = true;
+                continue;
+            }
+            __syncthreads();
+            border_pair_to_quads(a, upper ? cd : pend, upper ? ci : pend_ci, true, Plds, s_stack, s_out, rows);
+            has_pend = false;
+            continue;
+        }
+        __syncthreads();
         if (cd.n <= QP_LDS)
-            border_to_quad<true>(a, cd, ci, Plds, s_stack, s_out, s_outn, rows);
+            border_to_quad<true>(a, cd, ci, Plds, s_stack[0], s_out[0], s_outn, rows);
         else
-            border_to_quad<false>(a, cd, ci, a.pool + cd.pool_off, s_stack, s_out, s_outn, rows);
+            border_to_quad<false>(a, cd, ci, a.pool + cd.pool_off, s_stack[0], s_out[0], s_outn, rows);
+    }
+    if (has_pend) {   // no partner came: all 64 lanes on the one border
+        __syncthreads();
+        border_to_quad<true>(a, pend, pend_ci, Plds, s_stack[0], s_out[0], s_outn, rows);
     }
 }
 
@@ -1277,6 +1390,7 @@ void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const 
     a.cap_cdesc = b.cap_cdesc, a.cap_quads = b.cap_quads, a.nthr = p.nthr, a.width = g.width, a.height = g.height;
     a.trig_cnt = b.trig_cnt, a.walk_scratch = b.walk_scratch;
     a.nplanes = nframes * p.nthr;
+    a.dual = b.tune.quad_dual && a.nplanes > 8;   // a single frame has a wave per kept border anyway: all 64 lanes on one border are faster there
     // a handful of planes (one detect() per frame): a wave per kept border instead of a few waves that take the borders one after the other
     const int qb = a.nplanes <= 2 ? 128 : a.nplanes <= 8 ? 48 : b.tune.quad_blocks;
     a.qblocks = pass == 2 ? std::max(1, qb / 2) : qb;

@@ -303,6 +303,8 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
 // in flight a workgroup that needs a fifth of a CU's LDS waits for it, this kernel ran 0.41 ms in the stream against 0.06 alone (overlap trace).
 constexpr int OTSU_PITCH = 66;   // halfwords per bin row: 64 candidates + padding against bank conflicts
 constexpr int OTSU_BINS = 64;    // bins staged at a time
+// Round 4 measured a sweep that skips runs of empty bins once mu1 has reached its fixed point (bit-identical, a third of the divisions): the lane's
+// branches cost more than the divisions save - 93-106 us against 50 us for the 15 candidates of a 640x480 still, 0.43 against 0.41 ms per 1024-frame batch. Not kept.
 __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     latency_bound_priority();
     __shared__ uint16_t sh[OTSU_BINS * OTSU_PITCH];
@@ -316,7 +318,6 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
     const double scale = 1. / npx;
     const double mu = (double)(uint32_t)a.othr[idx] * scale;
     double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-    bool done = false;
     constexpr int DW = OTSU_BINS / 2;          // dwords of a candidate's row per stage
     constexpr int CPL = 64 / DW;               // candidates a load instruction covers
     for (int stage = 0; stage < 256 / OTSU_BINS; stage++) {
@@ -340,45 +341,55 @@ __global__ __launch_bounds__(64) void otsu_kernel(DecodeArgs a) {
             }
         }
         __syncthreads();
-        if (lane < cnt && !done) {
+        if (lane < cnt) {
             const uint16_t* h = sh + lane;
-            // The sweep is a chain of dependent fp64 divisions, one per bin (OpenCV's recurrence is order-dependent, so every bin that changes the
-            // state must be taken in order). A patch of a marker has two clusters of grey levels: most bins are EMPTY, and an empty bin (p_i = 0)
-            // only replaces mu1 by fl(fl(mu1 * q1) / q1): once that leaves mu1 unchanged, the state and sigma are those of the bin before - whose
-            // sigma the maximum already holds, and a tie does not move it - so the rest of the run of empty bins is skipped. Before the first
-            // occupied bin q1 = 0 and mu1 = 0 stay what they are; behind the last one q1 > 1 - eps holds for good and nothing is evaluated any
-            // more. Bit-identical to the plain sweep (tests/test_gpu_parity.py compares ids and thresholds with the oracle's), a third of its steps.
-            unsigned long long occ = 0;
-#pragma unroll 16
-            for (int ii = 0; ii < OTSU_BINS; ii++) occ |= (unsigned long long)(h[ii * OTSU_PITCH] != 0) << ii;
-            for (int ii = 0; ii < OTSU_BINS;) {
-                const int i = stage * OTSU_BINS + ii;
-                const bool empty = !((occ >> ii) & 1ull);
-                const int run_end = empty ? ((occ >> ii) ? ii + (int)__builtin_ctzll(occ >> ii) : OTSU_BINS) : ii + 1;   // first bin behind this run of empty bins
-                const double p_i = empty ? 0. : h[ii * OTSU_PITCH] * scale;
-                const double mu1_in = mu1;
-                mu1 *= q1;
-                q1 += p_i;
-                const double q2 = 1. - q1;
-                ii++;
-                if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) {
-                    if (q1 > 0.5) {   // all the mass is behind: every later bin takes this branch too and mu1 is never read again
-                        done = true;
-                        break;
+            // Sixteen bins at a time, in three passes, so that only what MUST be sequential sits on the chain of dependent operations. The reference's
+            // recurrence per bin is  mu1 = (mu1 * q1_old + i * p_i) / q1  (or mu1 * q1_old alone when a class is empty): a product, a sum and a
+            // division, each rounded. q1 (a running sum of the p_i) and the skip test do not depend on mu1, so pass A forms them and the
+            // denominator's part of the division ahead of the chain - the reciprocal of q1 refined by two Newton steps, exactly the first half of
+            // the fp64 division sequence the compiler emits (rcp, fma, fma, fma, fma); pass B is the chain: product, sum, and the numerator's half
+            // of that same sequence (q = a * r, e = fma(-q1, q, a), fma(e, r, q)) - the operands are far from the exponent range where the
+            // hardware sequence rescales (q1 in [1e-7, 1], a in [0, 255]), so this IS the compiler's division, bit for bit; pass C (mu2, sigma,
+            // the running maximum) follows off the chain. 5 dependent operations per bin instead of ~14.
+            constexpr int G = 16;
+#pragma unroll 1
+            for (int g0 = 0; g0 < OTSU_BINS; g0 += G) {
+                double q1v[G], rv[G], ipv[G], m1v[G];
+                uint32_t skip = 0;
+                const double q1_in = q1;
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int i = stage * OTSU_BINS + g0 + j;
+                    const double p_i = h[(g0 + j) * OTSU_PITCH] * scale;
+                    q1 += p_i;
+                    const double q2 = 1. - q1;
+                    if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) skip |= 1u << j;
+                    q1v[j] = q1, ipv[j] = i * p_i;
+                    const double r0 = __builtin_amdgcn_rcp(q1);
+                    const double r1 = __builtin_fma(r0, __builtin_fma(-q1, r0, 1.), r0);
+                    rv[j] = __builtin_fma(r1, __builtin_fma(-q1, r1, 1.), r1);
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const double t = mu1 * (j ? q1v[j - 1] : q1_in);
+                    const double a_ = t + ipv[j];
+                    const double q = a_ * rv[j];
+                    const double e = __builtin_fma(-q1v[j], q, a_);
+                    const double d = __builtin_fma(e, rv[j], q);
+                    mu1 = ((skip >> j) & 1u) ? t : d;
+                    m1v[j] = mu1;
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if ((skip >> j) & 1u) continue;
+                    const int i = stage * OTSU_BINS + g0 + j;
+                    const double q2 = 1. - q1v[j];
+                    const double mu2 = (mu - q1v[j] * m1v[j]) / q2;
+                    const double sigma = q1v[j] * q2 * (m1v[j] - mu2) * (m1v[j] - mu2);
+                    if (sigma > max_sigma) {
+                        max_sigma = sigma;
+                        max_val = i;
                     }
-                    if (empty) ii = run_end;   // q1 = 0: mu1 = 0 * 0 stays 0 through the run
-                    continue;
-                }
-                mu1 = (mu1 + i * p_i) / q1;
-                if (empty && mu1 == mu1_in) {   // fixed point: the remaining empty bins of the run change nothing
-                    ii = run_end;
-                    continue;
-                }
-                const double mu2 = (mu - q1 * mu1) / q2;
-                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                if (sigma > max_sigma) {
-                    max_sigma = sigma;
-                    max_val = i;
                 }
             }
         }

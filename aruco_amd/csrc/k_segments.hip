@@ -59,6 +59,9 @@ struct SegArgs {
     int seg_chunks, cyc_chunks;     // workgroups per plane of the per-node kernels (256 threads) / of the lap kernel (64 threads)
 };
 
+#ifdef SEG_STATS
+__device__ uint32_t g_seg_stats[4];   // debug variant: [0] run-rule fallbacks to memory, [1] max iterations of a wave, [2] block reloads, [3] sum of iterations over waves
+#endif
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr unsigned long long NONE64 = ~0ull;
 
@@ -107,10 +110,46 @@ __device__ __forceinline__ bool run_rule(const uint64_t* __restrict__ tiles, int
 __device__ __forceinline__ bool on_grid(uint32_t pos, int e, int grid_mask) {
     return (e & 2) ? ((pos & 0xFFFFu) & grid_mask) == 0 : ((pos >> 16) & grid_mask) == 0;   // N,S: column; W,E: row
 }
-__device__ __forceinline__ bool is_waypoint(const uint64_t* tiles, int tnx, uint32_t pos, int e, uint32_t m, int grid_mask, int width) {
+// The run rule from the lane's own 32x32 block in LDS (round 4): the thresholded image is made of 3-pixel bands, a run almost always ends within the block's
+// columns and the test is two row words; only a run that leaves the block goes back to the tiles in memory (nine tile reads per row - inside the step
+// loop those reads were what segment_kernel spent its time on: 116 us of a 430 us single-frame call). *decided = false: the block cannot tell.
+template <int LANES>
+__device__ __forceinline__ bool run_rule_block(const uint32_t* rows, int lane, const TileBlock& blk, uint32_t pos, int e, bool* decided) {
+    const int hole = e == 0;
+    const uint32_t zpos = pos + (hole ? 1u : 0u);
+    const int lx = (int)(zpos & 0xFFFFu) - blk.bx, ly = (int)(zpos >> 16) - blk.by;
+    *decided = false;
+    if (lx < 0 || lx > 31 || ly < 1 || ly > 31) return true;
+    const uint32_t mid = rows[ly * LANES + lane] >> lx, up = rows[(ly - 1) * LANES + lane] >> lx;
+    const int avail = 32 - lx;
+    if (!hole) {
+        const int L = (~mid) ? __builtin_ctz(~mid) : 32;          // run of set pixels starting at x
+        if (L >= avail) return true;                               // the run (or its right neighbour above) leaves the block
+        *decided = true;
+        const uint32_t mm = L >= 2 ? (((2u << L) - 1u) & ~3u) : 0u;   // blockers: row above, columns x+2 .. x+L
+        return (up & mm) == 0;
+    }
+    const int L = mid ? __builtin_ctz(mid) : 32;                   // run of clear pixels starting at x
+    if (L >= avail) return true;
+    *decided = true;
+    const uint32_t mm = L >= 2 ? (((1u << L) - 1u) & ~1u) : 0u;       // row above, columns x+1 .. x+L-1 must all be set
+    return (~up & mm) == 0;
+}
+template <int LANES>
+__device__ __forceinline__ bool run_rule_any(const uint64_t* tiles, int tnx, const uint32_t* rows, int lane, const TileBlock& blk, uint32_t pos, int e) {
+    bool decided;
+    const bool r = run_rule_block<LANES>(rows, lane, blk, pos, e, &decided);
+#ifdef SEG_STATS
+    if (!decided) atomicAdd(&g_seg_stats[0], 1u);
+#endif
+    return decided ? r : run_rule(tiles, tnx, pos, e);
+}
+template <int LANES>
+__device__ __forceinline__ bool is_waypoint(const uint64_t* tiles, int tnx, const uint32_t* rows, int lane, const TileBlock& blk, uint32_t pos, int e, uint32_t m,
+                                            int grid_mask, int width) {
     if (on_grid(pos, e, grid_mask)) return true;
-    if (e == 4 && (m & 0x1Eu) == 0) return run_rule(tiles, tnx, pos, 4);                                               // outer start: W,NW,N,NE clear
-    if (e == 0 && ((m >> 1) & 1u) && (int)(pos & 0xFFFFu) + 1 <= width - 2) return run_rule(tiles, tnx, pos, 0);    // hole start: z inside, N(z) set
+    if (e == 4 && (m & 0x1Eu) == 0) return run_rule_any<LANES>(tiles, tnx, rows, lane, blk, pos, 4);                                               // outer start: W,NW,N,NE clear
+    if (e == 0 && ((m >> 1) & 1u) && (int)(pos & 0xFFFFu) + 1 <= width - 2) return run_rule_any<LANES>(tiles, tnx, rows, lane, blk, pos, 0);    // hole start: z inside, N(z) set
     return false;
 }
 
@@ -138,7 +177,7 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
         uint8_t flag = 0;
         if (live) {
             a.stamp[nb + i] = NONE64;
-            if (rec.x & 1u) flag = run_rule(tiles, a.tnx, pos0, e0) ? 1 : 0;
+            if (rec.x & 1u) flag = run_rule_any<256>(tiles, a.tnx, rows, tid, blk, pos0, e0) ? 1 : 0;
             // not a node: isolated pixel (a one-point border, never kept) or a start candidate the run rule rejects off the grid
             if (m == 0 || (!flag && !on_grid(pos0, e0, a.grid_mask))) {
                 a.node[nb + i] = make_uint4(key, NONE32, 2u << 16, NONE32);
@@ -154,7 +193,13 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
         uint32_t pos = pos0, mn = NONE32, len = 0, next_key = NONE32;
         int from = e0;   // cracks after direction `from` (counter-clockwise) are still to come in this visit
         int step = 0;
+#ifdef SEG_STATS
+        uint32_t iters = 0;
+#endif
         while (__any(live)) {
+#ifdef SEG_STATS
+            iters++;
+#endif
             if (live) {
                 int k;
                 const int d = ccw_first(m, s, &k);
@@ -165,7 +210,7 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
                     if (dir & 1) continue;       // diagonal neighbours are not cracks
                     if (dir == 4) mn = min(mn, pos);
                     if (dir == 0) mn = min(mn, pos + 1u);
-                    if (is_waypoint(tiles, a.tnx, pos, dir, m, a.grid_mask, a.width)) {
+                    if (is_waypoint<256>(tiles, a.tnx, rows, tid, blk, pos, dir, m, a.grid_mask, a.width)) {
                         next_key = (pos << 2) | (uint32_t)(dir >> 1);
                         break;
                     }
@@ -179,9 +224,15 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
                     len++;
                 }
             }
+#ifdef SEG_STATS
+            if (__any(live && !tb_inside(blk, pos)) && (tid & 63) == 0) atomicAdd(&g_seg_stats[2], 1u);
+#endif
             if (__any(live && !tb_inside(blk, pos))) tb_load<256>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
             if (live) m = tb_mask<256>(rows, tid, blk, pos);
         }
+#ifdef SEG_STATS
+        if ((tid & 63) == 0) atomicMax(&g_seg_stats[1], iters), atomicAdd(&g_seg_stats[3], iters);
+#endif
         if (!is_node) continue;
         if (next_key == NONE32) {   // no waypoint within the bound: cannot happen for borders that cross the grid
             flag_overflow(a.counters, a.trig_cnt, plane, ST_SEGMENT_ERROR);
@@ -193,6 +244,12 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
 
 // Kernel S3: next key -> node index
 __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
+#ifdef SEG_STATS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.counters[6] = min(g_seg_stats[0], 65535u) | (min(g_seg_stats[2], 65535u) << 16), a.counters[7] = min(g_seg_stats[1], 65535u) | (min(g_seg_stats[3], 65535u) << 16);
+        g_seg_stats[0] = g_seg_stats[1] = g_seg_stats[2] = g_seg_stats[3] = 0;
+    }
+#endif
     int plane, chunk;
     if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);

@@ -72,12 +72,32 @@ def thread_scaling_leg(capi, frame_1080p, threads=(1, 4, 16), seconds=1.5):
     """The reference's call shape under load: T host threads, each with a detector of its own (MarkerDetector is not re-entrant, one object
     per thread: src/markerdetector.cpp:334,372-380), each calling detect() on one pinned 1080p host frame per call in a loop
     (utils/aruco_test.cpp:153-160's frame loop, T cameras). frames/s over all threads; ctypes releases the GIL during the call."""
+    import subprocess
+    import tempfile
     import threading
 
     import numpy as np
     import torch
 
-    out = {}
+    exe = os.path.join(ROOT, "build", "thread_bench")
+    if os.path.exists(exe):
+        # the C++ host program (tools/thread_bench.cpp, built by __graft_entry__.build()): no interpreter between the threads and the C ABI
+        with tempfile.NamedTemporaryFile(suffix=".raw", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tf:
+            tf.write(np.ascontiguousarray(frame_1080p).tobytes())
+            tf.flush()
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            env["GPU_MAX_HW_QUEUES"] = "16"
+            try:
+                r = subprocess.run([exe, tf.name, str(frame_1080p.shape[1]), str(frame_1080p.shape[0]), str(seconds)] + [str(t) for t in threads],
+                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+                if r.returncode == 0:
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    d["host"] = "C++ (tools/thread_bench.cpp)"
+                    return d
+                sys.stderr.write("thread_bench failed (%d): %s\n" % (r.returncode, r.stderr[-300:]))
+            except Exception as e:   # fall through to the Python threads
+                sys.stderr.write("thread_bench: %r\n" % (e,))
+    out = {"host": "python threads (ctypes releases the GIL during the call)"}
     for T in threads:
         pinned = [torch.empty(frame_1080p.shape, dtype=torch.uint8, pin_memory=True) for _ in range(T)]
         for p in pinned:
@@ -593,6 +613,16 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    # ---- replica pass, outside the timed region: the timed loop once more (same steps, same batches in flight, same result copies) with nothing
+    # but the threshold kernel's device-clock stamps on (no hipEvents between the kernels): the in-stream duration of its launches as
+    # rocprofv3 --kernel-trace reports it for `bench.py --profile-run` (profiles/<tag>_kernel_stats.csv)
+    handle.enable_timing(2)
+    for i in range(args.steps):
+        step(i)
+    drain(args.steps)
+    torch.cuda.synchronize()
+    rep_ms, rep_n = handle.threshold_exec_ms()
+    handle.enable_timing(False)
     # ---- instrumented passes, outside the timed region: per-kernel hipEvent intervals and the threshold kernel's device-clock span with
     # the same batches in flight, then one batch at a time (what rocprofv3 shows per dispatch when nothing else runs)
     gp_keep, gp = gp, None                      # the instrumented passes do not gather
@@ -616,7 +646,7 @@ def main():
         ktimes_iso = handle.kernel_times()
         iso_exec_ms, iso_exec_n = handle.threshold_exec_ms()
         handle.enable_timing(False)
-    fill = handle.debug_counters() if (args.clutter or "WALK_STATS" in build) else None
+    fill = handle.debug_counters() if args.clutter else None
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -633,7 +663,9 @@ def main():
         # also contains the time the dispatch queues behind the other batches' kernels.
         dom_ms = ktimes[dom]
         event_ms = dom_ms
-        if exec_n > 0:
+        if rep_n > 0:
+            dom_ms = rep_ms / rep_n
+        elif exec_n > 0:
             dom_ms = exec_ms / exec_n
         achieved = own * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         iso_ms = ktimes_iso.get(dom, dom_ms)
@@ -697,9 +729,10 @@ def main():
                          "algorithmic_bytes_formula": "W*H gray read + tiles_x*tiles_y*8 bit tiles + tiles_y*2*strips*8 bitmap + 2*Wp + 2*Hp border lines written "
                                                       "(bench.py: threshold_own_bytes; DESIGN.md 5)",
                          "frames_per_launch": per_launch, "launches_per_step": chunks, "avg_launch_ms": round(dom_ms, 4),
-                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the instrumented pass (%d batches in flight); "
-                                                 "profiles/: rocprofv3 average of the same kernel under bench.py --profile-run" % (exec_n, depth)
-                         if exec_n > 0 else "hipEvent interval on the launch stream",
+                         "avg_launch_ms_source": "device clock, first wave start to last wave end, %d launches of the replica pass (the timed loop again, %d batches in flight, "
+                                                 "no hipEvents); profiles/: rocprofv3 average of the same kernel under bench.py --profile-run" % (rep_n, depth)
+                         if rep_n > 0 else "device clock, launches of the hipEvent-instrumented pass" if exec_n > 0 else "hipEvent interval on the launch stream",
+                         "avg_launch_ms_event_pass": round(exec_ms / exec_n, 4) if exec_n > 0 else None,
                          "traffic_over_algorithmic": round(traffic / (own * per_launch), 3) if traffic else None,
                          "frac_traffic": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic and dom_ms > 0 else None,
                          "event_interval_ms": round(event_ms, 4),

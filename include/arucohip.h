@@ -265,6 +265,9 @@ int arucohip_debug_contour(arucohip_handle* h, int frame, int index, int* is_hol
                            int cap_points, int* n_points);
 /* Candidates after detectRectangles in reference order: integer quad, decoded id (-1 none), nRotations. */
 int arucohip_debug_candidates(arucohip_handle* h, int frame, float* quads0, int32_t* ids, int32_t* nrot, int cap, int* n);
+/* Otsu threshold (cv::threshold THRESH_OTSU inside the decoders, arucofidmarkers.cpp:169 / highlyreliablemarkers.cpp:346) of every candidate's patch,
+ * same order; -1 where the decode stage did not run for the candidate. */
+int arucohip_debug_otsu(arucohip_handle* h, int frame, int32_t* thr, int cap, int* n);
 
 /* Device list fill levels of the last batch: [0] border-start candidates, [1] borders kept, [2] contour points,
  * [3] overflow bits. For sizing arucohip_limits_t. */
@@ -300,7 +303,8 @@ int arucohip_threshold_exec_ms(arucohip_handle* h, double* total_ms, int* launch
  * ARUCO_MARKER_BENCHMARK stages (markerdetector.cpp:472-476): names via arucohip_stage_name. Returns count. */
 int arucohip_stage_times(arucohip_handle* h, float* ms, int cap);
 const char* arucohip_stage_name(int i);
-/* on != 0 starts recording (and resets the average); up to 32 batches are averaged. */
+/* on = 1 starts recording (and resets the average); up to 32 batches are averaged. on = 2: no hipEvents, only the device-clock stamps behind
+ * arucohip_threshold_exec_ms (an otherwise uninstrumented run). on = 0 stops both. */
 int arucohip_enable_timing(arucohip_handle* h, int on);
 /* Per-kernel average device time (ms per batch) since arucohip_enable_timing; names via arucohip_kernel_name. */
 int arucohip_kernel_times(arucohip_handle* h, float* ms, int cap);

@@ -334,3 +334,91 @@ def test_cluttered_stream_equals_the_oracle(env):
         assert set(t["id"] for t in truth[f]) == set(int(m["id"]) for m in got[f]), f
         total += len(got[f])
     assert total == 32 * 20
+
+
+def test_two_borders_per_wave_equal_one_border_per_wave(env, monkeypatch):
+    """Round 4: contour_quad takes two borders of at most 512 points per wave (one per half wave). On 16 cluttered and 16 flat 1080p frames the
+    candidates of every frame (quads in reference order, ids, rotations), the emitted contour points and the markers are byte-identical to
+    the one-border-per-wave path (ARUCOHIP_QUAD_DUAL=0), and the candidate quads equal the oracle's."""
+    import torch
+    from aruco_amd import synth
+    capi, orc = env["capi"], env["orc"]
+    fr_c, _ = synth.make_stream(16, seed=99, device="cuda", clutter=True)
+    fr_f, _ = synth.make_stream(16, seed=98, device="cuda")
+    torch.cuda.synchronize()
+    frames = np.concatenate([fr_c.cpu().numpy(), fr_f.cpu().numpy()])
+    res = {}
+    for dual in ("1", "0"):
+        monkeypatch.setenv("ARUCOHIP_QUAD_DUAL", dual)
+        h = capi.Handle(1920, 1080, max_batch=32)
+        try:
+            got = h.detect_batch_host(frames, cap=64)
+            assert h.debug_counters()["status"] == 0
+            cands = [h.debug_candidates(f) for f in range(32)]
+            conts = [h.debug_contours(f) for f in (0, 5, 17, 31)]
+            res[dual] = (got, cands, conts)
+        finally:
+            h.close()
+    monkeypatch.delenv("ARUCOHIP_QUAD_DUAL")
+    a, b = res["1"], res["0"]
+    for f in range(32):
+        assert a[0][f].tobytes() == b[0][f].tobytes(), f
+        for x, y in zip(a[1][f], b[1][f]):
+            assert x.tobytes() == y.tobytes(), f
+    for ca, cb in zip(a[2], b[2]):
+        assert len(ca) == len(cb) > 50
+        for x, y in zip(ca, cb):
+            assert x["hole"] == y["hole"] and x["start"] == y["start"] and x["pts"].tobytes() == y["pts"].tobytes()
+    o = orc.Oracle()
+    for f in (0, 9, 16, 31):
+        o.detect_raw(frames[f])
+        ref = o.candidates()
+        q = a[1][f][0]
+        assert len(ref) == len(q), f
+        for i, r in enumerate(ref):
+            assert np.array_equal(q[i], r["quad0"]), (f, i)     # integer quads, reference order
+            assert a[1][f][1][i] == r["id"], (f, i)
+
+
+def test_otsu_thresholds_of_every_candidate_equal_the_oracle(env):
+    """Round 4: otsu_kernel takes the denominator's half of the fp64 division (reciprocal of q1 + two Newton steps) off the chain of dependent
+    operations. The threshold it leaves for EVERY candidate - markers and rejected quads alike - of 8 cluttered and 8 flat 1080p frames and of the
+    reference's four stills equals getThreshVal_Otsu_8u's (oracle, order-dependent double recurrence) on the candidate's 56x56 patch."""
+    import torch
+    from aruco_amd import synth
+    from tests.util import load_case
+    capi, orc = env["capi"], env["orc"]
+    fr_c, _ = synth.make_stream(8, seed=7, device="cuda", clutter=True)
+    fr_f, _ = synth.make_stream(8, seed=8, device="cuda")
+    torch.cuda.synchronize()
+    frames = np.concatenate([fr_c.cpu().numpy(), fr_f.cpu().numpy()])
+    checked = 0
+    h = capi.Handle(1920, 1080, max_batch=16)
+    try:
+        h.detect_batch_host(frames, cap=64)
+        o = orc.Oracle()
+        for f in range(16):
+            q, ids, _ = h.debug_candidates(f)
+            thr = h.debug_otsu(f)
+            o.detect_raw(frames[f])
+            ref = o.candidates()
+            assert len(ref) == len(q) == len(thr), f
+            for i, r in enumerate(ref):
+                assert np.array_equal(q[i], r["quad0"]), (f, i)
+                assert thr[i] == orc.otsu(orc.warp(frames[f], r["quad0"], 56)), (f, i)
+                checked += 1
+    finally:
+        h.close()
+    for name in ("single", "board", "chessboard"):
+        g, _ = load_case(name)
+        h = capi.Handle(g.shape[1], g.shape[0], max_batch=1)
+        try:
+            h.detect(g)
+            q, _, _ = h.debug_candidates(0)
+            thr = h.debug_otsu(0)
+            for i in range(len(q)):
+                assert thr[i] == orc.otsu(orc.warp(g, q[i], 56)), (name, i)
+                checked += 1
+        finally:
+            h.close()
+    assert checked > 500

@@ -1,15 +1,29 @@
 #!/usr/bin/env python3
-"""A few single-frame detect() calls on the 640x480 'single' still, for a per-dispatch rocprofv3 trace of one call."""
+"""A few single-frame detect() calls for a per-dispatch rocprofv3 trace of one call (tools/trace_latency.sh):
+   latency_trace.py [single|board|1080p]   (the reference's 640x480 stills or one 1080p frame of the bench stream)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aruco_amd import capi
 from aruco_amd.fixtures import load_case
-g, _ = load_case("single")
-h = capi.Handle(640, 480, max_batch=1)
+case = sys.argv[1] if len(sys.argv) > 1 else "single"
+if case == "1080p":
+    from aruco_amd import synth
+    fr, _ = synth.make_stream(1, seed=4711, device="cpu")
+    g = fr[0].numpy()
+else:
+    g, _ = load_case(case)
+pinned = torch.empty(g.shape, dtype=torch.uint8, pin_memory=True)
+pinned.copy_(torch.from_numpy(g))
+g = pinned.numpy()
+h = capi.Handle(g.shape[1], g.shape[0], max_batch=1)
 for _ in range(30):
     h.detect(g)
 t0 = time.perf_counter()
 for _ in range(200):
-    h.detect(g)
-print("ms per call", (time.perf_counter() - t0) / 200 * 1e3)
+    m = h.detect(g)
+print("case", case, "markers", len(m), "ms per call", (time.perf_counter() - t0) / 200 * 1e3)
+import ctypes, numpy as np
+c = np.zeros(8, np.uint32)
+h.L.arucohip_debug_counters(h.h, c.ctypes.data_as(ctypes.c_void_p))
+print("debug counters", c.tolist(), "SEG_STATS variant: fallbacks", c[6] & 0xFFFF, "reloads", c[6] >> 16, "max wave iterations", c[7] & 0xFFFF, "sum of wave iterations", c[7] >> 16, "raw records", c[4])
