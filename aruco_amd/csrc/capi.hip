@@ -36,6 +36,7 @@ Tuning read_tuning() {
     t.fork_after = geti("ARUCOHIP_FORK_AFTER", 3);
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 12));
     t.quad_dual = geti("ARUCOHIP_QUAD_DUAL", 1) != 0;
+    t.seg_skip = geti("ARUCOHIP_SEG_SKIP", 1) != 0;
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
 #ifdef ARUCOHIP_STAGE_EXPERIMENT
@@ -280,7 +281,7 @@ static void free_all(arucohip_handle* h) {
     hipFree(h->buf.thr_stamps), hipFree(h->buf.thr_acc), hipFree(h->buf.thres_edge);
     hipFree(h->buf.thres), hipFree(h->buf.tiles), hipFree(h->buf.tile_bits), hipFree(h->buf.raw), hipFree(h->buf.trig), hipFree(h->buf.gen_buf), hipFree(h->zero_block), hipFree(h->buf.cdesc), hipFree(h->buf.pool);
     hipFree(h->buf.quads), hipFree(h->buf.cands), hipFree(h->buf.ncands), hipFree(h->buf.cand_list), hipFree(h->buf.iM), hipFree(h->buf.hist), hipFree(h->buf.othr), hipFree(h->buf.markers), hipFree(h->buf.nmarkers), hipFree(h->buf.marker_list);
-    hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
+    hipFree(h->buf.walk_scratch), hipFree(h->buf.node), hipFree(h->buf.skipn), hipFree(h->buf.stamp), hipFree(h->buf.hash), hipFree(h->buf.patches), hipFree(h->d_gray), hipFree(h->d_bgr), hipFree(h->d_erode), hipFree(h->d_canny), hipFree(h->d_umap_xy), hipFree(h->d_umap_f), hipFree(h->d_undist), hipFree(h->d_hrm), hipFree(h->d_user_dec), hipFree(h->d_small_f), hipFree(h->d_small_d), hipFree(h->d_small_i), hipFree(h->d_patch), hipFree(h->d_board), hipFree(h->d_gl);
     if (h->hu_list) hipHostFree(h->hu_list);
     if (h->hu_patches) hipHostFree(h->hu_patches);
     if (h->h_markers) hipHostFree(h->h_markers);
@@ -394,6 +395,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     if (b.seg_mode) {   // waypoint-segment pipeline only: a walker handle of 1024 frames would carry 5 GB of these for nothing
         ALLOC(b.raw, P * (size_t)b.cap_raw * sizeof(uint2));
         ALLOC(b.node, P * (size_t)b.cap_raw * sizeof(uint4));
+        if (lim->max_batch <= 2) ALLOC(b.skipn, P * (size_t)b.cap_raw * sizeof(uint4));
         ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
         ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
     }
@@ -772,8 +774,7 @@ static void run_walkers_and_quads(arucohip_handle* h, hipStream_t s, const Frame
 // runs kernels 2..8 after the masks and start candidates exist
 static void run_rectangles(arucohip_handle* h, const FrameGeom& g, int nframes, const DetectParams& dp) {
     if (h->buf.seg_mode) {
-        (void)hipMemsetAsync(h->buf.hash, 0xFF, (size_t)nframes * dp.nthr * (h->buf.hash_mask + 1) * sizeof(uint32_t), h->stream);
-        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);
+        launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf);   // also clears the planes' key -> node tables
         launch_segments(h->stream, g, nframes * dp.nthr, dp, h->buf);
     } else {
         launch_start_candidates(h->stream, g, nframes * dp.nthr, h->buf, dp.min_contour);
@@ -841,8 +842,7 @@ static int detect_core(arucohip_handle* h, const uint8_t* gray_dev, const FrameG
     if (h->ev_thr) HIPCHK(h, hipEventRecord(h->ev_thr, s));
     MARK(K_FILTER);
     if (b.seg_mode) {
-        HIPCHK(h, hipMemsetAsync(b.hash, 0xFF, (size_t)nframes * dp.nthr * (b.hash_mask + 1) * sizeof(uint32_t), s));
-        launch_start_candidates(s, g, nframes * dp.nthr, b);
+        launch_start_candidates(s, g, nframes * dp.nthr, b);   // also clears the planes' key -> node tables
         MARK(K_WALKERS);
         launch_segments(s, g, nframes * dp.nthr, dp, b);
         MARK(K_WALKERS_LONG);

@@ -126,6 +126,7 @@ struct Tuning {
     int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
     int ngens = 0;
     int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
+    int seg_skip = 1;          // ARUCOHIP_SEG_SKIP=0: the laps of the segment pipeline take one segment per hop also for one frame per call
     int quad_dual = 1;         // ARUCOHIP_QUAD_DUAL=0: one border per wave in contour_quad (round 3), 1: two borders of <= 512 points per wave
     int quad_blocks = 12;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad. One border per wave (rounds 1-3): 8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72 -> 24.
                                // Two borders per wave (round 4): a workgroup needs an even number of short borders to pair them all, so fewer, longer lists:
@@ -176,6 +177,7 @@ struct Buffers {
     int thr_stamp_on;       // stamps are taken (arucohip_enable_timing)
     uint32_t* walk_scratch; // checkpoint rings of the long walks [P][2][LONG_CAP][max_contour/16]
     uint4* node;            // [P][cap_raw] waypoint records of the segment pipeline
+    uint4* skipn;           // [P][cap_raw] a node's 8th successor, smallest key and visits of the 8 segments up to it (one frame per call: k_segments.hip)
     unsigned long long* stamp; // [P][cap_raw] (start key, start node, offset) of the start that owns the node
     uint32_t* hash;         // [P][hash_mask+1] node index by waypoint key
     uint32_t hash_mask;

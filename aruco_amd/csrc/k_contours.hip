@@ -75,6 +75,8 @@ struct CandArgs {
     uint32_t* counters;
     uint32_t cap_raw, cap_trig;
     int seg_mode, grid_mask;
+    uint32_t* hash;          // segment mode: the plane's key -> node table, cleared here (segment_kernel fills it: one memset node less per call)
+    uint32_t hash_size;
 };
 
 constexpr int CAND_THREADS = 256;
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandArgs a) {
     const int ntiles = ntx * nty;
     const uint64_t COL0 = 0x0101010101010101ull, COL7 = 0x8080808080808080ull;
     const uint32_t half = a.seg_mode ? a.cap_raw : a.cap_trig / 2;
+    if (a.hash)
+        for (uint32_t i = blockIdx.x * CAND_THREADS + threadIdx.x; i < a.hash_size; i += gridDim.x * CAND_THREADS) a.hash[(size_t)plane * a.hash_size + i] = 0xFFFFFFFFu;
     uint2* const out = a.seg_mode ? a.raw + (size_t)plane * a.cap_raw : a.trig + (size_t)plane * a.cap_trig;
     uint32_t* const out_cnt = (a.seg_mode ? a.raw_cnt : a.trig_cnt) + plane * TRIG_CNT_STRIDE;
 
@@ -425,6 +429,7 @@ void launch_start_candidates(hipStream_t s, const FrameGeom& g, int nplanes, con
     a.trig = b.trig, a.trig_cnt = b.trig_cnt, a.raw = b.raw, a.raw_cnt = b.raw_cnt, a.counters = b.counters;
     a.cap_raw = b.cap_raw, a.cap_trig = b.cap_trig;
     a.seg_mode = b.seg_mode, a.grid_mask = b.grid_mask;
+    a.hash = b.seg_mode ? b.hash : nullptr, a.hash_size = b.hash_mask + 1;
     const int ntiles = (a.tnx - 1) * (a.tny - 1);
     // a single frame has the chip to itself: a tile per thread; a batch of planes: four tiles per thread, at most cand_chunks workgroups per plane
     const int maxchunks = nplanes <= 2 ? 256 : b.tune.cand_chunks;

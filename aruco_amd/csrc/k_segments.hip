@@ -57,6 +57,7 @@ struct SegArgs {
     uint32_t* trig_cnt;             // per-plane counter lines (TC_CDESC, TC_POOL)
     int min_contour, max_contour;
     int seg_chunks, cyc_chunks;     // workgroups per plane of the per-node kernels (256 threads) / of the lap kernel (64 threads)
+    uint4* skipn;                   // non-null: laps take SKIP segments per hop (one frame per call)
 };
 
 #ifdef SEG_STATS
@@ -122,18 +123,24 @@ __device__ __forceinline__ bool run_rule_block(const uint32_t* rows, int lane, c
     if (lx < 0 || lx > 31 || ly < 1 || ly > 31) return true;
     const uint32_t mid = rows[ly * LANES + lane] >> lx, up = rows[(ly - 1) * LANES + lane] >> lx;
     const int avail = 32 - lx;
+    // a blocker inside the block's columns settles the rule whatever the run does beyond them (the interior of a hole is a clear run of tens of
+    // pixels - with a clear pixel above it after one or two); without one the run has to end inside the block
     if (!hole) {
         const int L = (~mid) ? __builtin_ctz(~mid) : 32;          // run of set pixels starting at x
-        if (L >= avail) return true;                               // the run (or its right neighbour above) leaves the block
+        const int hi = min(L, avail - 1);                          // blockers: row above, columns x+2 .. x+L
+        const uint32_t mm = hi >= 2 ? (((2u << hi) - 1u) & ~3u) : 0u;
+        if (up & mm) return *decided = true, false;
+        if (L >= avail) return true;                               // no blocker so far and the run leaves the block: the tiles decide
         *decided = true;
-        const uint32_t mm = L >= 2 ? (((2u << L) - 1u) & ~3u) : 0u;   // blockers: row above, columns x+2 .. x+L
-        return (up & mm) == 0;
+        return true;
     }
     const int L = mid ? __builtin_ctz(mid) : 32;                   // run of clear pixels starting at x
+    const int hi = min(L - 1, avail - 1);                          // row above, columns x+1 .. x+L-1 must all be set
+    const uint32_t mm = hi >= 1 ? (((2u << hi) - 1u) & ~1u) : 0u;
+    if (~up & mm) return *decided = true, false;
     if (L >= avail) return true;
     *decided = true;
-    const uint32_t mm = L >= 2 ? (((1u << L) - 1u) & ~1u) : 0u;       // row above, columns x+1 .. x+L-1 must all be set
-    return (~up & mm) == 0;
+    return true;
 }
 template <int LANES>
 __device__ __forceinline__ bool run_rule_any(const uint64_t* tiles, int tnx, const uint32_t* rows, int lane, const TileBlock& blk, uint32_t pos, int e) {
@@ -203,17 +210,32 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
             if (live) {
                 int k;
                 const int d = ccw_first(m, s, &k);
-                // clear neighbours examined in this visit: directions s+1 .. d-1; keep those after `from`
-                const int t = (from - s) & 7;   // `from` is the t-th examined direction (t >= 1), or 0 at a fresh visit
-                for (int q = t + 1; q <= k; q++) {
-                    const int dir = (s + q) & 7;
-                    if (dir & 1) continue;       // diagonal neighbours are not cracks
-                    if (dir == 4) mn = min(mn, pos);
-                    if (dir == 0) mn = min(mn, pos + 1u);
-                    if (is_waypoint<256>(tiles, a.tnx, rows, tid, blk, pos, dir, m, a.grid_mask, a.width)) {
-                        next_key = (pos << 2) | (uint32_t)(dir >> 1);
-                        break;
+                // Clear neighbours examined in this visit: directions s+1 .. s+k, of which those after `from` are still to come; `from` is the t-th
+                // examined direction (t >= 1), or 0 at a fresh visit. Round 4: the visit's cracks as bit sets instead of a loop over them (the loop
+                // with the waypoint test inside ran up to seven times per step for the slowest lane of the wave). Relative bit r <-> direction
+                // s + 1 + r, so that the lowest set bit is the first crack in examination order.
+                const int t = (from - s) & 7;
+                const uint32_t sh = (uint32_t)(s + 1) & 7u;
+                const uint32_t rel = ((1u << k) - 1u) & ~((1u << t) - 1u);                       // examined and still to come
+                const uint32_t ex = ((rel << sh) | (rel << sh >> 8)) & 0x55u;                    // absolute directions, cracks only (E, N, W, S)
+                if (ex) {
+                    const uint32_t x = pos & 0xFFFFu, y = pos >> 16;
+                    uint32_t way = (((y & (uint32_t)a.grid_mask) == 0) ? 0x11u : 0u) | (((x & (uint32_t)a.grid_mask) == 0) ? 0x44u : 0u);   // W, E cracks on grid rows; N, S on grid columns
+                    // start-candidate cracks off the grid (3x3 rule of kernel 1) are waypoints when they pass the run rule
+                    if ((ex & ~way & 0x10u) && (m & 0x1Eu) == 0 && run_rule_any<256>(tiles, a.tnx, rows, tid, blk, pos, 4)) way |= 0x10u;
+                    if ((ex & ~way & 0x01u) && ((m >> 1) & 1u) && (int)x + 1 <= a.width - 2 && run_rule_any<256>(tiles, a.tnx, rows, tid, blk, pos, 0)) way |= 0x01u;
+                    const uint32_t hit = ex & way;
+                    uint32_t seen = ex;                                                           // cracks examined up to and including the first waypoint
+                    if (hit) {
+                        const uint32_t hr = ((hit | (hit << 8)) >> sh) & 0xFFu;                   // back to examination order
+                        const uint32_t r = (uint32_t)__builtin_ctz(hr);
+                        const uint32_t dir = (sh + r) & 7u;
+                        next_key = (pos << 2) | (dir >> 1);
+                        const uint32_t upto = (2u << r) - 1u;
+                        seen = ex & ((upto << sh) | (upto << sh >> 8));
                     }
+                    if (seen & 0x10u) mn = min(mn, pos);
+                    if (seen & 0x01u) mn = min(mn, pos + 1u);
                 }
                 if (next_key != NONE32 || ++step > max_steps) {
                     live = false;
@@ -282,6 +304,46 @@ __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
 // (start key, start node, visits from the start): the true start has the smallest key of its cycle and completes its
 // lap, so afterwards every node of a kept border carries the true start's stamp; false starts drop out at the first
 // node whose segment holds a smaller key and can only leave larger stamps behind.
+// One frame per call (round 4): a lap is a chain of dependent node reads, 0.24 us each - 48 us for a 640x480 photograph, 95 us for the board still, a
+// fifth of the call. skip_kernel gives every node its SKIP-th successor with the smallest key and the visits of the SKIP segments in between; a lap
+// then takes SKIP segments per hop while the smallest key of the stretch stays above its own, stamps only the nodes it lands on, and walks single
+// segments once the stretch holds its own key (the start's crack is examined in the segment before the start node: the lap is about to close).
+// fill_kernel afterwards carries every stamp SKIP - 1 nodes forward (atomicMin like the laps: the true start's stamps - the smallest key, and per
+// node the smallest offset - win), so every node of a kept border ends with the stamp the single-segment lap gives it.
+constexpr int SKIP = 8;
+__global__ __launch_bounds__(256) void skip_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const size_t nb = (size_t)plane * a.cap_raw;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += a.seg_chunks * blockDim.x) {
+        uint32_t j = i, mn = NONE32, len = 0;
+        for (int h = 0; h < SKIP; h++) {
+            const uint4 nd = a.node[nb + j];
+            mn = min(mn, nd.y), len += nd.z & 0xFFFFu, j = nd.x;
+        }
+        a.skipn[nb + i] = make_uint4(j, mn, len, 0u);
+    }
+}
+__global__ __launch_bounds__(256) void fill_kernel(SegArgs a) {
+    int plane, chunk;
+    if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
+    const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);
+    const size_t nb = (size_t)plane * a.cap_raw;
+    for (uint32_t i = chunk * blockDim.x + threadIdx.x; i < n; i += a.seg_chunks * blockDim.x) {
+        const unsigned long long st = a.stamp[nb + i];
+        if (st == NONE64) continue;
+        const unsigned long long tag = st & ~0x3FFFull;
+        uint32_t off = (uint32_t)(st & 0x3FFFull), j = i;
+        for (int h = 1; h < SKIP; h++) {
+            const uint4 nd = a.node[nb + j];
+            off += nd.z & 0xFFFFu, j = nd.x;
+            if (off > 0x3FFFu) break;
+            atomicMin(&a.stamp[nb + j], tag | off);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
     int plane, chunk;
     if (!plane_of_block(a.nplanes, a.cyc_chunks, &plane, &chunk)) return;
@@ -293,9 +355,26 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         const int hole = (key & 3u) == 0;
         const uint32_t k0 = pos0 + (hole ? 1u : 0u);     // the scan transition: outer -> the pixel, hole -> clear pixel right of it
         const unsigned long long tag = ((unsigned long long)k0 << 34) | ((unsigned long long)i << 14);
-        uint32_t total = 0, j = i;
+        uint32_t total = 0, j = i, hops = 0;
         bool ok = true;
-        for (uint32_t hops = 0;; hops++) {
+        if (a.skipn) {   // SKIP segments per hop until the stretch ahead holds this start's own key
+            for (;; hops++) {
+                const uint4 sk = a.skipn[nb + j];
+                if (sk.y == k0) break;
+                if (sk.y < k0 || hops > 4u * (uint32_t)a.max_contour) {
+                    ok = false;
+                    break;
+                }
+                atomicMin(&a.stamp[nb + j], tag | total);
+                total += sk.z;
+                if (total >= (uint32_t)a.max_contour) {
+                    ok = false;
+                    break;
+                }
+                j = sk.x;
+            }
+        }
+        for (; ok; hops++) {
             const uint4 nd = a.node[nb + j];
             if (nd.y < k0 || hops > 4u * (uint32_t)a.max_contour) {
                 ok = false;
@@ -333,6 +412,9 @@ __global__ __launch_bounds__(64) void cycle_kernel(SegArgs a) {
         a.node[nb + i].w = gslot;   // emit_kernel finds the descriptor through the start node
     }
 }
+// Round 4 measured the laps hopping through a copy of the plane's node table in LDS (one workgroup per frame): a hop costs what it costs through the
+// L2 (0.24 us: the chain is the atomic's address, the compare and the loop, not the read), and one CU then takes every lap of the frame - 48.8 against 48.6 us for a
+// 640x480 still, 219 against 60 us for the board still. Not kept.
 
 // Kernel S5: one lane per node of a kept border: write the points of its visits
 __global__ __launch_bounds__(256) void emit_kernel(SegArgs a) {
@@ -394,6 +476,7 @@ static void fill_seg_args(SegArgs& a, const FrameGeom& g, int nplanes, const Det
     a.cdesc = b.cdesc, a.pool = b.pool, a.counters = b.counters, a.cap_cdesc = b.cap_cdesc, a.cap_pool = b.cap_pool, a.trig_cnt = b.trig_cnt;
     a.min_contour = p.min_contour, a.max_contour = p.max_contour;
     seg_chunks_for(nplanes, &a.seg_chunks, &a.cyc_chunks);
+    a.skipn = (nplanes <= 2 && b.tune.seg_skip) ? b.skipn : nullptr;
 }
 
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b) {
@@ -402,7 +485,9 @@ void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const Detec
     const int groups = (nplanes + 7) / 8 * 8;
     hipLaunchKernelGGL(segment_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(link_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
+    if (a.skipn) hipLaunchKernelGGL(skip_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(cycle_kernel, dim3(groups * a.cyc_chunks), dim3(64), 0, s, a);
+    if (a.skipn) hipLaunchKernelGGL(fill_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(emit_kernel, dim3(groups * a.seg_chunks), dim3(256), 0, s, a);
 }
 

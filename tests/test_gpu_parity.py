@@ -389,6 +389,32 @@ def test_segment_pipeline_mode(env, monkeypatch):
         ref.close()
 
 
+@pytest.mark.parametrize("grid", ["8", "16", "32"])
+def test_segment_pipeline_grids_on_1080p_frames(env, monkeypatch, grid):
+    """The waypoint-segment pipeline (the default for one frame per call since round 4 up to 1080p; round 4 rebuilt its step: the cracks of a visit as
+    bit sets, the run rule from the lane's block) at the grid spacings 8 / 16 / 32: every kept border of a cluttered and a flat 1080p frame, of dense
+    blobs and of salt-and-pepper noise equals cv::findContours' (start pixel, direction, every point), with the reference's size filter and a permissive one."""
+    capi, synth = env["capi"], env["synth"]
+    monkeypatch.setenv("ARUCOHIP_CONTOURS", "segments")
+    monkeypatch.setenv("ARUCOHIP_GRID", grid)
+    h = capi.Handle(1920, 1080, max_batch=1)
+    monkeypatch.delenv("ARUCOHIP_CONTOURS")
+    monkeypatch.delenv("ARUCOHIP_GRID")
+    try:
+        fc, _ = synth.make_stream(1, seed=31, device="cpu", clutter=True)
+        ff, _ = synth.make_stream(1, seed=32, device="cpu")
+        total = 0
+        for g in (fc[0].numpy(), ff[0].numpy()):
+            total += _contour_check(env, h, g, False, 0.04, 0.5)
+            total += _contour_check(env, h, g, False, 0.02, 0.5)      # (a permissive filter on these frames outgrows the candidate lists)
+        rng = np.random.RandomState(11)
+        total += _contour_check(env, h, blob_image(rng, 479, 641, 4), True, 0.004, 1.0)
+        total += _contour_check(env, h, ((rng.rand(200, 300) > 0.5) * 255).astype(np.uint8), True, 0.002, 1.0)
+        assert total > 600
+    finally:
+        h.close()
+
+
 def test_chunk_streams(env, monkeypatch):
     """ARUCOHIP_STREAMS=3: a batch cut into chunks on forked streams gives the bytes of the single-stream batch, and the
     per-frame getters / batched board pose find their frame's worker."""
