@@ -1214,7 +1214,10 @@ __device__ __forceinline__ void border_to_quad(const QuadArgs& a, const ContourD
 // traffic, two reductions on the DPP network, the fp64 test, the barriers; about 150 instructions against 10 per 64 points scanned - per border; here
 // the two halves run the same instruction stream on their own border. Every quantity that was wave-uniform is uniform per half; `valid` is false
 // for a half without a border. Same arithmetic, same scan order, same tie breaks as border_to_quad.
-constexpr int DUAL_MAX = 512;
+#ifndef DUAL_MAX_N
+#define DUAL_MAX_N 512
+#endif
+constexpr int DUAL_MAX = DUAL_MAX_N;   // 1024 (with QP_LDS_N=2048) measured: see profiles/r04_experiments.txt
 __device__ __forceinline__ void border_pair_to_quads(const QuadArgs& a, const ContourDesc& cd, const uint32_t ci, const bool valid, short2* Pbase, int (*s_stack)[16][2],
                                                      short2 (*s_out)[12], uint32_t* rows) {
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
@@ -1231,8 +1234,8 @@ __device__ __forceinline__ void border_pair_to_quads(const QuadArgs& a, const Co
         const int ncp = (count + CK - 1) / CK;
         const uint32_t* ckp = cd.ck_off == 0xFFFFFFFFu ? (const uint32_t*)(a.pool + cd.pool_off) - ncp : a.walk_scratch + cd.ck_off;
         const uint32_t* rb = rows + lane - 64;
-        const int k = hl;
-        if (valid && k < ncp) {
+        for (int k = hl; k < (DUAL_MAX + CK - 1) / CK; k += 32) {   // one round for borders of up to 512 points
+            if (!(valid && k < ncp)) continue;
             const uint32_t c = ckp[k];
             const uint32_t pos = (c & 0x3FFFu) | (((c >> 14) & 0x3FFFu) << 16);
             const int n0 = k * CK, n1 = min(n0 + CK, count);

@@ -539,6 +539,8 @@ def main():
         if gp is not None:
             gp.drain()
 
+    if args.profile_run:
+        handle.enable_timing(2)                 # device-clock stamps of the threshold launches only (no events): the same launches rocprofv3 times
     for i in range(args.warmup):
         step(i)
     drain(args.warmup)
@@ -605,8 +607,10 @@ def main():
             raise SystemExit("gathered markers: %d of about %d" % (tot, rendered * world))
 
     if args.profile_run:
+        pr_ms, pr_n = handle.threshold_exec_ms()
+        handle.enable_timing(False)
         if rank == 0:
-            print(json.dumps({"profile_run": True, "build": build, "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s", "steps": args.steps,
+            print(json.dumps({"profile_run": True, "build": build, "threshold_device_clock_avg_ms": round(pr_ms / pr_n, 4) if pr_n else None, "threshold_launches_stamped": pr_n, "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s", "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "batches_in_flight": depth, "frames_per_launch": B,
                               "note": "every dispatch of this process is an in-stream launch at the bench's default depth (no instrumented passes)"}), flush=True)
         if world > 1:
@@ -784,7 +788,7 @@ def main():
             oc = {}
             for key, extra in (("config3_fps", ["--config", "3", "--steps", "20", "--warmup", "5"]),    # like the headline: five batches in flight fill and drain inside the timed steps
                                ("config4_fps", ["--config", "4", "--steps", "30", "--warmup", "6"]),   # 128-frame batches, six in flight: 12 steps are two rounds
-                               ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "8", "--warmup", "3"]),
+                               ("config2_pinned_h2d_fps", ["--host-frames", "--steps", "16", "--warmup", "5"]),   # 45 ms per step: five batches in flight fill and drain inside the timed steps
                                ("config2_clutter_fps", ["--clutter", "--steps", "20", "--warmup", "5"])):
                 d = run_leg(extra)
                 if "error" in d:

@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/p_lat
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/p_lat -- python3 tools/latency_trace.py ${1:-single} > gpurun_out/lat_run.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/p_lat -- python3 tools/latency_trace.py ${1:-single} ${2:-} ${3:-} > gpurun_out/lat_run.log 2>&1
 python3 - <<'PY'
 import csv, glob
 k = glob.glob("/tmp/p_lat/*/*kernel_trace.csv")[0]
