@@ -410,7 +410,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(b.iM, (size_t)b.cap_flat * 9 * sizeof(double));
     ALLOC(b.hist, (size_t)b.cap_flat * 256 * sizeof(uint16_t));
     ALLOC(b.othr, (size_t)b.cap_flat * sizeof(int32_t));
-    ALLOC(b.markers, F * b.cap_markers * sizeof(arucohip_marker_t));
+    ALLOC(b.markers, (F * b.cap_markers + 1) * sizeof(arucohip_marker_t));   // + the header slot of a one-frame call (k_finalize.hip: write_hdr)
     ALLOC(b.nmarkers, F * sizeof(int32_t));
     ALLOC(b.marker_list, F * (size_t)b.cap_markers * sizeof(uint32_t));
     {
@@ -430,7 +430,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
     ALLOC(h->d_small_i, 64 * sizeof(int));
     ALLOC(h->d_patch, 128 * 128);
 #undef ALLOC
-    if ((e = hipHostMalloc((void**)&h->h_markers, F * b.cap_markers * sizeof(arucohip_marker_t))) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc((void**)&h->h_markers, (F * b.cap_markers + 1) * sizeof(arucohip_marker_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc((void**)&h->h_n, F * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc((void**)&h->h_counters, (CNT_FIXED + F) * sizeof(uint32_t))) != hipSuccess) return bail(e);
     for (auto& set : h->ev)
@@ -1074,9 +1074,8 @@ static int detect_one_graphed(arucohip_handle* h, const uint8_t* frame, int W, i
         const Buffers& b = h->buf;
         hipError_t e = hipSuccess;
         if (rc == ARUCOHIP_OK) {
-            e = hipMemcpyAsync(h->h_markers, b.markers, (size_t)b.cap_markers * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h->h_n, b.nmarkers, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h->h_counters, b.counters, CNT_FIXED * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+            // ONE copy: the markers and, in the slot behind them, the count and the status word finalize_kernel left there
+            e = hipMemcpyAsync(h->h_markers, b.markers, ((size_t)b.cap_markers + 1) * sizeof(arucohip_marker_t), hipMemcpyDeviceToHost, h->stream);
         }
         const hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
         if (rc != ARUCOHIP_OK || e != hipSuccess || e2 != hipSuccess || !graph || hipGraphInstantiate(&h->fgraph.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -1091,6 +1090,9 @@ static int detect_one_graphed(arucohip_handle* h, const uint8_t* frame, int W, i
     *handled = true;
     HIPCHK(h, hipGraphLaunch(h->fgraph.exec, h->stream));
     h->last_w = W, h->last_h = H, h->last_frames = 1, h->last_nthr = dp.nthr, h->last_gray = gray_dev, h->last_geom = g;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int32_t* hdr = (const int32_t*)(h->h_markers + h->buf.cap_markers);
+    h->h_n[0] = hdr[0], h->h_counters[CNT_STATUS] = (uint32_t)hdr[1];
     return collect_batch_host(h, 1, out, cap, n_out);
 }
 

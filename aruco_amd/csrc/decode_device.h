@@ -13,17 +13,24 @@ namespace ah {
 // The 8x8 systems of HOMOGRAPHY_GROUP lanes at a time live in LDS, element-major: element k of a lane's matrix at k * GROUP + (lane % GROUP), so the lanes
 // of a group never collide on a bank. A wave solves its 64 candidates group after group (round 3: all 64 at once took 37 KB, and with the batches in
 // flight a workgroup that wants a quarter of a CU's LDS waits for it: 0.61 ms in the stream against 0.07 alone).
+// One frame per call (round 4): a single workgroup has the CU's LDS to itself, so all 64 lanes solve at once (frame_candidates_kernel<64>: 46 -> 2x us for the
+// 48 candidates of a 1080p frame).
 constexpr int HOMOGRAPHY_GROUP = 16;
-struct LaneMat {
+template <int G>
+struct LaneMatT {
     double* base;
     int lane;
-    __device__ __forceinline__ double& operator[](int k) const { return base[k * HOMOGRAPHY_GROUP + (lane & (HOMOGRAPHY_GROUP - 1))]; }
+    __device__ __forceinline__ double& operator[](int k) const { return base[k * G + (lane & (G - 1))]; }
 };
-constexpr int HOMOGRAPHY_LDS_DOUBLES = 64 * HOMOGRAPHY_GROUP + 8 * HOMOGRAPHY_GROUP;   // A (8 x 8) and b (8) of a group
+using LaneMat = LaneMatT<HOMOGRAPHY_GROUP>;
+template <int G>
+constexpr int homography_lds_doubles() { return 64 * G + 8 * G; }   // A (8 x 8) and b (8) of a group
+constexpr int HOMOGRAPHY_LDS_DOUBLES = homography_lds_doubles<HOMOGRAPHY_GROUP>();
 
 // qx / qy: the candidate's integer corners; iM: 9 doubles. Gaussian elimination with partial pivoting, same operation order as the CPU
 // restatement of cv::getPerspectiveTransform + the inversion cv::warpPerspective starts with.
-__device__ __forceinline__ void homography_lane(const int16_t* qx, const int16_t* qy, int ws, const LaneMat& A, const LaneMat& b, double* iM) {
+template <typename Mat>
+__device__ __forceinline__ void homography_lane(const int16_t* qx, const int16_t* qy, int ws, const Mat& A, const Mat& b, double* iM) {
     const double d = (double)(float)(ws - 1);
     const double dxs[4] = {0, d, d, 0}, dys[4] = {0, 0, d, d};
     for (int i = 0; i < 64; i++) A[i] = 0;

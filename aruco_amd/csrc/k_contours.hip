@@ -1435,12 +1435,13 @@ __device__ __forceinline__ float quad_perimeter_i(const int16_t* x, const int16_
     return sum;
 }
 
+template <int HG>   // lanes that solve their candidate's homography at a time (decode_device.h): 16 for batches, 64 for one frame per call
 __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
     latency_bound_priority();
     // one LDS region, two lives: the quads of the frame while they are ranked and thinned out, then the 8x8 systems of the homography solve
     // (decode_device.h) of up to 64 candidates at a time
     constexpr int PHASE1_BYTES = MAXQ * (8 + 8 + 4 + 4 + 2 + 1 + 1);
-    constexpr int BIG_DOUBLES = HOMOGRAPHY_LDS_DOUBLES > (PHASE1_BYTES + 7) / 8 ? HOMOGRAPHY_LDS_DOUBLES : (PHASE1_BYTES + 7) / 8;
+    constexpr int BIG_DOUBLES = homography_lds_doubles<HG>() > (PHASE1_BYTES + 7) / 8 ? homography_lds_doubles<HG>() : (PHASE1_BYTES + 7) / 8;
     __shared__ double s_big[BIG_DOUBLES];
     int16_t(*sx)[4] = (int16_t(*)[4])s_big;
     int16_t(*sy)[4] = sx + MAXQ;
@@ -1543,14 +1544,14 @@ __global__ __launch_bounds__(64) void frame_candidates_kernel(FrameArgs a) {
         }
     }
     __syncthreads();
-    const LaneMat A{s_big, lane}, b{s_big + 64 * HOMOGRAPHY_GROUP, lane};
+    const LaneMatT<HG> A{s_big, lane}, b{s_big + 64 * HG, lane};
 #pragma unroll
     for (int r = 0; r < PER_LANE; r++) {
         if (r * WAVE >= n) break;                       // wave-uniform
         const int k = r * WAVE + lane;
-        for (int g = 0; g < WAVE / HOMOGRAPHY_GROUP; g++) {   // one group of lanes at a time: they share the LDS the systems sit in
-            if (r * WAVE + g * HOMOGRAPHY_GROUP >= n) break;
-            if (lane / HOMOGRAPHY_GROUP == g && k < n && base + (uint32_t)k < a.cap_flat)
+        for (int g = 0; g < WAVE / HG; g++) {   // one group of lanes at a time: they share the LDS the systems sit in
+            if (r * WAVE + g * HG >= n) break;
+            if (lane / HG == g && k < n && base + (uint32_t)k < a.cap_flat)
                 homography_lane(qx[r], qy[r], a.ws, A, b, a.iM + (size_t)(base + (uint32_t)k) * 9);
         }
     }
@@ -1562,7 +1563,10 @@ void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, con
     a.cand_list = b.cand_list, a.cap_flat = b.cap_flat;
     a.cap_quads = b.cap_quads, a.cap_cands = b.cap_cands;
     a.iM = b.iM, a.ws = p.warp_size;
-    hipLaunchKernelGGL(frame_candidates_kernel, dim3(nframes), dim3(64), 0, s, a);
+    if (nframes <= 2)
+        hipLaunchKernelGGL(frame_candidates_kernel<64>, dim3(nframes), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(frame_candidates_kernel<HOMOGRAPHY_GROUP>, dim3(nframes), dim3(64), 0, s, a);
 }
 
 }  // namespace ah

@@ -37,6 +37,7 @@ struct FinalArgs {
     arucohip_marker_t* out;   // [frames][out_cap] or null
     int32_t* n_out;           // [frames] or null
     int out_cap;
+    int write_hdr;            // one frame per call: count and status word also go to the slot behind the marker array, so ONE copy brings everything to the host
 };
 
 __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalArgs a) {
         for (int t = 0; t < a.nthr; t++) fst |= a.trig_cnt[(size_t)(frame * a.nthr + t) * TRIG_CNT_STRIDE + TC_STATUS];
         if (fst) n = -1;
         a.nmarkers[frame] = n;   // required count; the host clamps and reports ARUCOHIP_E_CAPACITY
+        if (a.write_hdr && frame == 0) {
+            int32_t* hdr = (int32_t*)(a.markers + (size_t)gridDim.x * a.cap_markers);
+            hdr[0] = n, hdr[1] = (int32_t)atomicOr(&a.counters[CNT_STATUS], 0u);   // every earlier kernel's overflow bits and this one's
+        }
         if (a.n_out) a.n_out[frame] = n;
         // work list of the pose kernel (order across frames is irrelevant); never more than F * cap_markers entries
         const int kept = min(n, a.cap_markers);
@@ -122,6 +127,7 @@ void launch_finalize(hipStream_t s, const FrameGeom& g, int nframes, const Detec
                      int32_t* n_out) {
     FinalArgs a;
     a.out = out, a.out_cap = out_cap, a.n_out = n_out;
+    a.write_hdr = nframes == 1;
     a.cands = b.cands, a.ncands = b.ncands, a.markers = b.markers, a.nmarkers = b.nmarkers, a.counters = b.counters, a.marker_list = b.marker_list;
     a.trig_cnt = b.trig_cnt, a.nthr = p.nthr;
     a.cap_cands = b.cap_cands, a.cap_markers = b.cap_markers;
