@@ -183,7 +183,7 @@ __device__ __forceinline__ uint8_t warp_gather(const uint8_t* src, size_t row_st
 // WS = 56 (the reference's default markerWarpSize, src/markerdetector.cpp:246): a patch is 7 x 7 blocks, a step of the loop is one block row, so the
 // column terms of the seven blocks are formed once per candidate and the row terms once per block row, and no pixel needs a bounds test (round 3:
 // the stream is bound by vector-instruction issue, and these were a third of the kernel's). WS = 0: any size, everything per pixel.
-template <int WS>
+template <int WS, int ROWS>
 __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const uint32_t idx, uint32_t* hist, const double* siM, const int lane) {
     const uint32_t e = a.cand_list[idx];
     const uint8_t* src = a.gray + (size_t)(e >> 16) * a.frame_stride;
@@ -206,17 +206,29 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
             ax[q] = m0 * x, bx[q] = m3 * x, cx[q] = m6 * x;
         }
         uint8_t* prow = patch + byl * WS + bxl;
-        for (int BY = 0; BY < GQ; BY++) {
-            const int y = BY * 8 + byl;
-            const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
-            uint8_t v[GQ];
+        // ROWS block rows of gathers are issued before any of them is consumed: 1 for batches (registers = resident waves), 2 for one frame per call,
+        // where a candidate's wave has the SIMD to itself and the kernel's time is the chain of its gather round trips (7 -> 4 of them)
+        for (int BY0 = 0; BY0 < GQ; BY0 += ROWS) {
+            uint8_t v[ROWS][GQ];
 #pragma unroll
-            for (int q = 0; q < GQ; q++) v[q] = warp_gather<true>(src, a.row_stride, W, H, X0, Y0, W0, ax[q], bx[q], cx[q], true);
+            for (int rr = 0; rr < ROWS; rr++) {
+                const int BY = min(BY0 + rr, GQ - 1);   // the odd last round repeats the last row's addresses (their values are not used twice)
+                const int y = BY * 8 + byl;
+                const double X0 = m1 * y + m2, Y0 = m4 * y + m5, W0 = m7 * y + m8;
 #pragma unroll
-            for (int q = 0; q < GQ; q++) {
-                prow[BY * 8 * WS + q * 8] = v[q];
-                psum += v[q];
-                atomicAdd(&myhist[v[q] >> 2], 1u << (8 * (v[q] & 3)));
+                for (int q = 0; q < GQ; q++) v[rr][q] = warp_gather<true>(src, a.row_stride, W, H, X0, Y0, W0, ax[q], bx[q], cx[q], true);
+            }
+#pragma unroll
+            for (int rr = 0; rr < ROWS; rr++) {
+                const int BY = BY0 + rr;
+                if (BY < GQ) {
+#pragma unroll
+                    for (int q = 0; q < GQ; q++) {
+                        prow[BY * 8 * WS + q * 8] = v[rr][q];
+                        psum += v[rr][q];
+                        atomicAdd(&myhist[v[rr][q] >> 2], 1u << (8 * (v[rr][q] & 3)));
+                    }
+                }
             }
         }
     } else {
@@ -268,6 +280,7 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
     if (lane == 0) a.othr[idx] = (int32_t)psum;
 }
 
+template <int ROWS>
 __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
     throughput_bound_priority();
     __shared__ uint32_t hist[HCOPIES * HPITCH];
@@ -290,9 +303,9 @@ __global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
         if (lane < 9) siM[lane] = a.iM[(size_t)idx * 9 + lane];
         __syncthreads();
         if (a.ws == 8 * GQ && a.row_stride * (size_t)a.height < ((size_t)1 << 32))
-            warp_hist_candidate<8 * GQ>(a, idx, hist, siM, lane);
+            warp_hist_candidate<8 * GQ, ROWS>(a, idx, hist, siM, lane);
         else
-            warp_hist_candidate<0>(a, idx, hist, siM, lane);
+            warp_hist_candidate<0, 1>(a, idx, hist, siM, lane);
     }
 }
 
@@ -485,7 +498,13 @@ void launch_decode(hipStream_t s, const uint8_t* gray, const FrameGeom& g, int n
     const int lane_blocks = (int)((b.cap_flat + 63) / 64);
     const int wave_blocks = (int)std::min<uint32_t>(b.cap_flat, (uint32_t)nframes * 48u);
     // the inverse homographies are there already: frame_candidates_kernel solved them (b.iM)
-    hipLaunchKernelGGL(warp_hist_kernel, dim3(wave_blocks), dim3(64), 0, s, a);
+    // one frame per call: the XCD-run unpacking sends list entries 0..47 to the slots of XCD 0 only - with 48 workgroups six of them took all the
+    // candidates, eight one after the other (47 us for a 1080p frame); a workgroup per slot of the first run instead
+    const int warp_blocks = nframes <= 2 ? (int)std::min<uint32_t>(b.cap_flat, 8u * XCD_RUN) : wave_blocks;
+    if (nframes <= 2)
+        hipLaunchKernelGGL(warp_hist_kernel<2>, dim3(warp_blocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(warp_hist_kernel<1>, dim3(warp_blocks), dim3(64), 0, s, a);
     if (p.decoder == ARUCOHIP_DECODER_USER) return;   // the host callback decodes the patches (capi.hip: user_decode_stage)
     hipLaunchKernelGGL(otsu_kernel, dim3(lane_blocks), dim3(64), 0, s, a);
     if (p.decoder == 1) {
