@@ -37,6 +37,7 @@ Tuning read_tuning() {
     t.quad_blocks = std::max(1, geti("ARUCOHIP_QUAD_BLOCKS", 12));
     t.quad_dual = geti("ARUCOHIP_QUAD_DUAL", 1) != 0;
     t.seg_skip = geti("ARUCOHIP_SEG_SKIP", 1) != 0;
+    t.gen_xcd = geti("ARUCOHIP_GEN_XCD", 1) != 0;
     t.threshold_wide = geti("ARUCOHIP_THRESHOLD_WIDE", 1) != 0;
     t.threshold_eo = geti("ARUCOHIP_THRESHOLD_EO", 1) != 0;
 #ifdef ARUCOHIP_STAGE_EXPERIMENT
@@ -399,7 +400,7 @@ int arucohip_create_ex(const arucohip_params_t* params, int device, const arucoh
         ALLOC(b.stamp, P * (size_t)b.cap_raw * sizeof(unsigned long long));
         ALLOC(b.hash, P * (size_t)(b.hash_mask + 1) * sizeof(uint32_t));
     }
-    ALLOC(b.gen_buf, P * (size_t)b.long_cap * 4 * 20);   // [2 kinds][2 parities][P * long_cap] walk states (16 B) + ring ids (4 B)
+    ALLOC(b.gen_buf, ((P + 7) / 8 * 8) * (size_t)b.long_cap * 4 * 20);   // [2 kinds][2 parities][planes rounded up to 8 * long_cap] walk states (16 B) + ring ids (4 B)
     ALLOC(b.cdesc, P * (size_t)b.cap_cdesc * sizeof(ContourDesc));
     ALLOC(b.pool, P * (size_t)b.cap_pool * sizeof(short2));
     ALLOC(b.quads, F * b.cap_quads * sizeof(Quad));

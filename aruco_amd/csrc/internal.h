@@ -126,6 +126,7 @@ struct Tuning {
     int gens[32] = {};         // ARUCOHIP_GENS: steps per generation of long walks
     int ngens = 0;
     int fork_after = 3;        // ARUCOHIP_FORK_AFTER: generations on the main stream
+    int gen_xcd = 1;           // ARUCOHIP_GEN_XCD=0: one generation list for the whole chip (rounds 1-3) instead of one per XCD
     int seg_skip = 1;          // ARUCOHIP_SEG_SKIP=0: the laps of the segment pipeline take one segment per hop also for one frame per call
     int quad_dual = 1;         // ARUCOHIP_QUAD_DUAL=0: one border per wave in contour_quad (round 3), 1: two borders of <= 512 points per wave
     int quad_blocks = 12;      // ARUCOHIP_QUAD_BLOCKS: workgroups per plane of contour_quad. One border per wave (rounds 1-3): 8: 0.93 ms, 16: 0.68, 24: 0.60, 32: 0.72 -> 24.
@@ -236,7 +237,7 @@ struct WalkFork {
 };
 bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 size_t walk_scratch_words(int nplanes, const DetectParams& p, uint32_t long_cap);   // capacity launch_walkers needs in Buffers::walk_scratch
-constexpr size_t GEN_CNT_WORDS = 2 * 32 * 32;                     // words of Buffers::gen_cnt
+constexpr size_t GEN_CNT_WORDS = 2 * 32 * 32 * 8;                 // words of Buffers::gen_cnt: [2 kinds][GEN_MAX + 2 generations][8 sublists] lines of 32 words
 void launch_segments(hipStream_t s, const FrameGeom& g, int nplanes, const DetectParams& p, const Buffers& b);
 void launch_contour_quads(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b, int pass = 0);
 void launch_frame_candidates(hipStream_t s, const FrameGeom& g, int nframes, const DetectParams& p, const Buffers& b);

@@ -460,6 +460,7 @@ struct WalkArgs {
     uint32_t* gen_ring;    // [2 kinds][2 parities][gen_cap]
     uint32_t* gen_cnt;     // [(kind * (GEN_MAX + 2) + generation) * GEN_CNT_STRIDE] entries of each list
     uint32_t gen_cap;      // entries per list
+    int gen_nx;            // sublists per list: 8 = one per XCD (a walk stays on the XCD its plane's first pass, tiles and contour_quad live on), 1 = one list
     int leash;             // steps every candidate gets in the first pass
     int gen, gen_steps;    // generation this launch processes (>= 1) and the steps it may take per walk
     int gen_blocks;        // 64-lane workgroups per kind in this launch (each loops over its share of the list)
@@ -471,6 +472,16 @@ struct WalkArgs {
 };
 
 enum WalkResult { WR_BAD = 0, WR_CLOSED = 1, WR_LIMIT = 2 };
+
+// Generation lists (round 4): [kind][parity][gen_nx sublists][gen_cap / gen_nx] and one counter line per (kind, generation, sublist). With gen_nx = 8 sublist x holds
+// the walks of the planes with plane % 8 == x - the planes whose first pass ran on XCD x (walker_kernel's unpacking) - and the generation workgroups with
+// blockIdx % 8 == x, which the hardware deals to XCD x, take exactly that sublist: a plane's tiles are then only ever read through ONE XCD's L2, by the first
+// pass, every generation and contour_quad alike (until round 4 a generation wave held walks of 64 different planes, whichever XCD it ran on).
+constexpr int GEN_NX_MAX = 8;
+__device__ __forceinline__ uint32_t gen_cnt_index(int kind, int gen, int x) { return (uint32_t)(((kind * (GEN_MAX + 2) + gen) * GEN_NX_MAX + x) * GEN_CNT_STRIDE); }
+__device__ __forceinline__ size_t gen_list_base(const WalkArgs& a, int kind, int parity, int x) {
+    return ((size_t)(kind * 2 + parity) * a.gen_nx + x) * (a.gen_cap / a.gen_nx);
+}
 
 // A checkpoint lets any lane resume the walk at step k*CK: pixel and the direction that points at the previous pixel.
 __device__ __forceinline__ uint32_t pack_ck(uint32_t pos, int s) { return (pos & 0x3FFFu) | ((pos >> 16) << 14) | ((uint32_t)s << 28); }
@@ -720,12 +731,13 @@ __device__ __forceinline__ void walk_short(const WalkArgs& a, int plane, int chu
             const unsigned long long bal = __ballot(longw);
             if (bal) {   // one atomic per wave on the list's counter
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&a.gen_cnt[((HOLE ? 1 : 0) * (GEN_MAX + 2) + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+                const int gx = a.gen_nx > 1 ? (plane & (GEN_NX_MAX - 1)) : 0;
+                if (lane == 0) base = atomicAdd(&a.gen_cnt[gen_cnt_index(HOLE ? 1 : 0, 1, gx)], (uint32_t)__popcll(bal));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (longw) {
                     const uint32_t at = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    if (at < a.gen_cap) {
-                        const size_t li = ((size_t)(HOLE ? 1 : 0) * 2 + 1) * a.gen_cap + at;   // parity of generation 1
+                    if (at < a.gen_cap / a.gen_nx) {
+                        const size_t li = gen_list_base(a, HOLE ? 1 : 0, 1, a.gen_nx > 1 ? (plane & (GEN_NX_MAX - 1)) : 0) + at;   // parity of generation 1
                         a.gen_state[li] = make_uint4(tkey, pos, pos1, n | ((uint32_t)s << 16));
                         a.gen_ring[li] = ring;
                     } else {
@@ -768,11 +780,14 @@ __global__ __launch_bounds__(64) void walker_kernel(WalkArgs a) {
 template <bool HOLE>
 __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, uint32_t* rows) {
     const int kind = HOLE ? 1 : 0, lane = threadIdx.x;
-    const uint32_t count = min(a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen) * GEN_CNT_STRIDE], a.gen_cap);
-    const size_t src = ((size_t)kind * 2 + (a.gen & 1)) * a.gen_cap, dst = ((size_t)kind * 2 + ((a.gen + 1) & 1)) * a.gen_cap;
+    // gen_blocks is a multiple of 8: workgroup b of this kind runs on XCD b % 8 and takes sublist b % 8 (gen_nx = 8) with the other gen_blocks / 8 - 1 of its XCD
+    const int gx = a.gen_nx > 1 ? (chunk & (GEN_NX_MAX - 1)) : 0;
+    const uint32_t sub = a.gen_nx > 1 ? (uint32_t)chunk >> 3 : (uint32_t)chunk, nsub = a.gen_nx > 1 ? (uint32_t)a.gen_blocks >> 3 : (uint32_t)a.gen_blocks;
+    const uint32_t count = min(a.gen_cnt[gen_cnt_index(kind, a.gen, gx)], a.gen_cap / a.gen_nx);
+    const size_t src = gen_list_base(a, kind, a.gen & 1, gx), dst = gen_list_base(a, kind, (a.gen + 1) & 1, gx);
     const uint32_t nmax = (uint32_t)a.max_contour;
     const size_t plane_tiles = (size_t)a.tnx * a.tny;
-    for (uint32_t base = (uint32_t)chunk * 64u; base < count; base += (uint32_t)a.gen_blocks * 64u) {
+    for (uint32_t base = sub * 64u; base < count; base += nsub * 64u) {
         const bool live = base + lane < count;
         const uint4 st = live ? a.gen_state[src + base + lane] : make_uint4(0x00200021u, 0x00200020u, 0u, 0u);
         const uint32_t ring = live ? a.gen_ring[src + base + lane] : 0u;
@@ -792,7 +807,7 @@ __device__ __forceinline__ void walk_generation(const WalkArgs& a, int chunk, ui
         const unsigned long long bal = __ballot(again);
         if (bal) {
             uint32_t at0 = 0;
-            if (lane == 0) at0 = atomicAdd(&a.gen_cnt[(kind * (GEN_MAX + 2) + a.gen + 1) * GEN_CNT_STRIDE], (uint32_t)__popcll(bal));
+            if (lane == 0) at0 = atomicAdd(&a.gen_cnt[gen_cnt_index(kind, a.gen + 1, gx)], (uint32_t)__popcll(bal));
             at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
             if (again) {
                 const size_t li = dst + at0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));   // at most as many entries as this list had
@@ -834,7 +849,9 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
     // generation lists: [2 kinds][2 parities][gen_cap] states (16 B) followed by the ring ids (4 B); a list can never
     // hold more walks than rings exist
     a.long_cap = b.long_cap;
-    a.gen_cap = (uint32_t)((size_t)nplanes * b.long_cap);
+    // one sublist per XCD when the batch gives every XCD planes to work on; a few planes (one frame per call with the walkers) keep one list for the whole chip
+    a.gen_nx = (nplanes >= 64 && b.tune.gen_xcd) ? GEN_NX_MAX : 1;
+    a.gen_cap = (uint32_t)((size_t)((nplanes + 7) / 8 * 8) * b.long_cap);
     a.gen_state = (uint4*)b.gen_buf;
     a.gen_ring = (uint32_t*)(a.gen_state + 4 * (size_t)a.gen_cap);
     a.gen = 0, a.gen_steps = 0;
@@ -882,7 +899,7 @@ bool launch_walkers(hipStream_t s, const WalkFork& fk, const FrameGeom& g, int n
         // plane's ~1000 candidates reach generation 1), fewer for the thin late generations; surplus workgroups exit at once
         const int before = done - a.gen_steps;   // steps every walk of this generation has behind it
         const int per_plane_x16 = before < 200 ? 64 : before < 450 ? 40 : before < 1100 ? 24 : 4;   // walks per plane and kind / 4, rough upper bounds
-        a.gen_blocks = std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2));
+        a.gen_blocks = (std::max(64, std::min(8192, (nplanes * per_plane_x16 * 4 + 63) / 64 / 2)) + 7) / 8 * 8;
         hipLaunchKernelGGL(walker_long_kernel, dim3(2 * a.gen_blocks), dim3(64), 0, cur, a);
     }
     if (forked) (void)hipEventRecord(fk.joined, fk.side);

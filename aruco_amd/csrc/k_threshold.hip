@@ -560,6 +560,8 @@ __device__ __forceinline__ void threshold_eo_body(const ThrArgs& a) {
     int r_next = r_begin;
     const uint8_t* p_next = src + (size_t)min(max(r_next, 0), H - 1) * a.row_stride;
     auto issue_loads = [&](const int kp) {
+        // (round 4: the same loads as non-temporal loads - so that the gray rows, read once, would not evict the tiles and pools the gather kernels re-read -
+        // changed nothing in the stream and cost this kernel 5 %: profiles/r04_experiments.txt 7)
         G[kp] = *(const uint4*)(p_next + xa);
         GH[kp] = *(const uint32_t*)(p_next + hxa);
         if (r_next >= 0 && r_next < H - 1) p_next += a.row_stride;
