@@ -280,8 +280,11 @@ __device__ __forceinline__ void warp_hist_candidate(const DecodeArgs& a, const u
     if (lane == 0) a.othr[idx] = (int32_t)psum;
 }
 
+#ifndef WARP_WAVES_N
+#define WARP_WAVES_N 2   // waves per SIMD the register allocator aims at (170 VGPRs unconstrained = 2)
+#endif
 template <int ROWS>
-__global__ __launch_bounds__(64) void warp_hist_kernel(DecodeArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WARP_WAVES_N, WARP_WAVES_N))) void warp_hist_kernel(DecodeArgs a) {
     throughput_bound_priority();
     __shared__ uint32_t hist[HCOPIES * HPITCH];
     __shared__ double siM[9];

@@ -219,7 +219,10 @@ __device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int l
 
 // one wave per decoded candidate, taken from the flat candidate list of the batch (a grid over every candidate slot of
 // every frame would be 90 % empty workgroups)
-__global__ __launch_bounds__(64) void refine_lines_kernel(LinesArgs a) {
+#ifndef LINES_WAVES_N
+#define LINES_WAVES_N 3   // waves per SIMD the register allocator aims at (129 VGPRs unconstrained = 3)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LINES_WAVES_N, LINES_WAVES_N))) void refine_lines_kernel(LinesArgs a) {
     latency_bound_priority();
     const int lane = threadIdx.x;
     const uint32_t nlist = min(a.counters[CNT_NCAND], a.cap_flat);
