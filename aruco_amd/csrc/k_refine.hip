@@ -220,7 +220,8 @@ __device__ __forceinline__ void refine_one(const LinesArgs& a, uint32_t e, int l
 // one wave per decoded candidate, taken from the flat candidate list of the batch (a grid over every candidate slot of
 // every frame would be 90 % empty workgroups)
 #ifndef LINES_WAVES_N
-#define LINES_WAVES_N 3   // waves per SIMD the register allocator aims at (129 VGPRs unconstrained = 3)
+#define LINES_WAVES_N 4   // waves per SIMD the register allocator is held to: 127 VGPRs without a spill instead of 129 = four resident waves instead of three
+                          // (round 4: 0.183 -> 0.153 ms alone, +1.8 % frames/s; the same for warp_hist - 170 -> 168 VGPRs, three waves - spills and gains nothing)
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LINES_WAVES_N, LINES_WAVES_N))) void refine_lines_kernel(LinesArgs a) {
     latency_bound_priority();
