@@ -60,9 +60,6 @@ struct SegArgs {
     uint4* skipn;                   // non-null: laps take SKIP segments per hop (one frame per call)
 };
 
-#ifdef SEG_STATS
-__device__ uint32_t g_seg_stats[4];   // debug variant: [0] run-rule fallbacks to memory, [1] max iterations of a wave, [2] block reloads, [3] sum of iterations over waves
-#endif
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr unsigned long long NONE64 = ~0ull;
 
@@ -146,9 +143,6 @@ template <int LANES>
 __device__ __forceinline__ bool run_rule_any(const uint64_t* tiles, int tnx, const uint32_t* rows, int lane, const TileBlock& blk, uint32_t pos, int e) {
     bool decided;
     const bool r = run_rule_block<LANES>(rows, lane, blk, pos, e, &decided);
-#ifdef SEG_STATS
-    if (!decided) atomicAdd(&g_seg_stats[0], 1u);
-#endif
     return decided ? r : run_rule(tiles, tnx, pos, e);
 }
 template <int LANES>
@@ -200,13 +194,7 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
         uint32_t pos = pos0, mn = NONE32, len = 0, next_key = NONE32;
         int from = e0;   // cracks after direction `from` (counter-clockwise) are still to come in this visit
         int step = 0;
-#ifdef SEG_STATS
-        uint32_t iters = 0;
-#endif
         while (__any(live)) {
-#ifdef SEG_STATS
-            iters++;
-#endif
             if (live) {
                 int k;
                 const int d = ccw_first(m, s, &k);
@@ -246,15 +234,9 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
                     len++;
                 }
             }
-#ifdef SEG_STATS
-            if (__any(live && !tb_inside(blk, pos)) && (tid & 63) == 0) atomicAdd(&g_seg_stats[2], 1u);
-#endif
             if (__any(live && !tb_inside(blk, pos))) tb_load<256>(tiles, a.tnx, a.tny, pos, rows, tid, blk);
             if (live) m = tb_mask<256>(rows, tid, blk, pos);
         }
-#ifdef SEG_STATS
-        if ((tid & 63) == 0) atomicMax(&g_seg_stats[1], iters), atomicAdd(&g_seg_stats[3], iters);
-#endif
         if (!is_node) continue;
         if (next_key == NONE32) {   // no waypoint within the bound: cannot happen for borders that cross the grid
             flag_overflow(a.counters, a.trig_cnt, plane, ST_SEGMENT_ERROR);
@@ -266,12 +248,6 @@ __global__ __launch_bounds__(256) void segment_kernel(SegArgs a) {
 
 // Kernel S3: next key -> node index
 __global__ __launch_bounds__(256) void link_kernel(SegArgs a) {
-#ifdef SEG_STATS
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.counters[6] = min(g_seg_stats[0], 65535u) | (min(g_seg_stats[2], 65535u) << 16), a.counters[7] = min(g_seg_stats[1], 65535u) | (min(g_seg_stats[3], 65535u) << 16);
-        g_seg_stats[0] = g_seg_stats[1] = g_seg_stats[2] = g_seg_stats[3] = 0;
-    }
-#endif
     int plane, chunk;
     if (!plane_of_block(a.nplanes, a.seg_chunks, &plane, &chunk)) return;
     const uint32_t n = min(a.raw_cnt[plane * TRIG_CNT_STRIDE], a.cap_raw);

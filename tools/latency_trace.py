@@ -28,7 +28,3 @@ t0 = time.perf_counter()
 for _ in range(200):
     m = h.detect(g, K=K, dist=dist, marker_size=msize)
 print("case", case, "markers", len(m), "ms per call", (time.perf_counter() - t0) / 200 * 1e3)
-import ctypes, numpy as np
-c = np.zeros(8, np.uint32)
-h.L.arucohip_debug_counters(h.h, c.ctypes.data_as(ctypes.c_void_p))
-print("debug counters", c.tolist(), "SEG_STATS variant: fallbacks", c[6] & 0xFFFF, "reloads", c[6] >> 16, "max wave iterations", c[7] & 0xFFFF, "sum of wave iterations", c[7] >> 16, "raw records", c[4])
